@@ -1,0 +1,236 @@
+/*
+ * amplihip.h -- C ABI of libamplihip.so, the MI355X (gfx950) engine behind AmpliPy's
+ * trim + pileup + call path.
+ *
+ * AmpliPy (the reference) has no FFI of its own: its hot path is three Python function
+ * seams called once per read from run_amplipy's loop (AmpliPy.py:896-915):
+ *     trim_read(s, min_primer_start, max_primer_end, max_primer_len, min_quality, window)
+ *                                                         AmpliPy.py:426-687, called :907
+ *     update_base_counts(symbol_counts_at_ref_pos, s, min_quality)
+ *                                                         AmpliPy.py:690-753, called :915
+ *     alleles_from_counts(symbol_counts) + calling loop   AmpliPy.py:756-771, :917-952
+ * plus find_overlapping_primers (AmpliPy.py:174-209) which builds trim_read's two tables.
+ * A per-read FFI call would cost more than the work, so the replacement is batch-level:
+ * one call takes a packed structure-of-arrays batch of reads and performs, for every read
+ * in order, exactly what :907 and :915 do.  Each entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds to AmpliPy.py.
+ *
+ * Conventions
+ *   - every function returns AMP_OK (0) or a negative amp_rc; nothing throws or aborts
+ *   - the caller owns every buffer it passes; a ctx owns its device memory
+ *   - one ctx per device; a ctx is not thread-safe; different ctxs are independent
+ *   - there is NO CPU fallback: amp_ctx_create fails with AMP_ENODEV without a GPU
+ *   - all integers little-endian, arrays contiguous
+ */
+#ifndef AMPLIHIP_H
+#define AMPLIHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMP_ABI_VERSION 1
+#define AMP_NSYM 6 /* count-table columns, in this order: A C G T N '-'  (AmpliPy.py:892) */
+#define AMP_SEQ_ALIGN 8 /* every read starts on a multiple of 8 bases in seq/qual */
+
+typedef enum amp_rc {
+    AMP_OK = 0,
+    AMP_EINVAL = -1,    /* bad argument (null pointer, negative size, window < 1 ...) */
+    AMP_ENOMEM = -2,    /* host or device allocation failed */
+    AMP_EHIP = -3,      /* a HIP runtime call failed (see amp_last_error) */
+    AMP_ENODEV = -4,    /* no usable gfx950 device */
+    AMP_ESTATE = -5,    /* call order violated (e.g. trim requested before amp_set_primers) */
+    AMP_EOVERFLOW = -6, /* an output buffer supplied by the caller is too small */
+    AMP_ERCCL = -7      /* RCCL not available / collective failed */
+} amp_rc;
+
+/*
+ * Per-read status: the inputs on which the reference raises.  The
+ * engine reports the condition instead of a result; amp_read_status_exception() names the
+ * Python exception class AmpliPy raises for it.  When any read of a batch has a non-zero
+ * status the batch's count contribution is unspecified (the reference would have died).
+ */
+typedef enum amp_read_status {
+    AMP_RS_OK = 0,
+    AMP_RS_INDEX_REF = 1,   /* IndexError: reference coordinate outside [0, ref_len)   :450-451, :715, :745, :753 */
+    AMP_RS_INDEX_PAIRS = 2, /* IndexError: insertion run reaches the end of the pairs   :734 */
+    AMP_RS_INDEX_QUERY = 3, /* IndexError: query index beyond the stored SEQ/QUAL       :718 */
+    AMP_RS_KEY_BASE = 4,    /* KeyError: counted base is not one of A C G T N           :753 */
+    AMP_RS_NO_SEQ = 5,      /* AttributeError: SEQ is '*'                               :702 */
+    AMP_RS_NO_QUAL = 6,     /* TypeError: QUAL is '*'                                   :561-562, :718 */
+    AMP_RS_CLIP = 7,        /* ValueError: hard clip inside soft clip (pysam accessor)  :561, :700-701 */
+    AMP_RS_CIGAR_OP = 8,    /* IndexError: CIGAR op code >= 9                           :378, :404, :474 */
+    AMP_RS_TYPE = 9         /* TypeError: None arithmetic (insertion followed by a deletion at ref 0) :736 */
+} amp_read_status;
+
+/* bits of trim_flags[i]: trim_read's three return values (AmpliPy.py:687) */
+#define AMP_TRIM_PRIMER_START 1u
+#define AMP_TRIM_PRIMER_END 2u
+#define AMP_TRIM_QUALITY 4u
+
+typedef struct amp_ctx amp_ctx;
+
+/* One insertion allele observation (AmpliPy.py:730-748): the string is
+ * SEQ[q_from:q_to] of read `read` (bounds already resolved, 0 <= q_from <= q_to <= l_seq),
+ * counted at reference position ref_pos. */
+typedef struct amp_ins_event {
+    int32_t ref_pos;
+    uint32_t read; /* row in the batch, plus the batch's read_base (amp_process_batch*) */
+    int32_t q_from;
+    int32_t q_to;
+} amp_ins_event;
+
+/*
+ * Packed read batch.  Rows are the reads the reference's loop does not skip (mapped, with a
+ * CIGAR: AmpliPy.py:902).  seq is 4-bit BAM codes "=ACMGRSVTWYHKDBN", high nibble first;
+ * qual is Phred bytes, first byte 0xFF = QUAL '*'; l_seq 0 = SEQ '*'.  Offsets in `seq_off`
+ * are in BASES and index both qual (bytes) and seq (nibbles); each must be a multiple of
+ * AMP_SEQ_ALIGN.  cig is BAM's `len<<4 | op`.
+ */
+typedef struct amp_reads {
+    int64_t n_reads;
+    const int32_t *pos;       /* [n]   0-based leftmost coordinate (reference_start) */
+    const uint16_t *flag;     /* [n]   SAM FLAG; bits 0x1 and 0x10 are read */
+    const int32_t *tlen;      /* [n]   template_length */
+    const uint32_t *lseq;     /* [n]   query_length */
+    const uint64_t *cig_off;  /* [n+1] */
+    const uint32_t *cig;      /* [cig_off[n]] */
+    const uint64_t *seq_off;  /* [n+1] */
+    const uint8_t *seq;       /* [seq_off[n]/2] */
+    const uint8_t *qual;      /* [seq_off[n]] */
+} amp_reads;
+
+/*
+ * Per-read results of trim_read (AmpliPy.py:426-687) and of the write filter's
+ * reference_length (AmpliPy.py:910).  Read i's new CIGAR is written at
+ * new_cig + cig_off[i] + 3*i, new_ncig[i] ops long (a trim adds at most 3 ops), so
+ * new_cig needs cig_off[n] + 3*n entries.  Any pointer may be NULL to skip that output.
+ */
+typedef struct amp_trim_out {
+    int32_t *new_pos;     /* [n] */
+    uint32_t *new_ncig;   /* [n] */
+    uint32_t *new_cig;    /* [cig_off[n] + 3n] */
+    int32_t *ref_len;     /* [n] reference_length after trimming */
+    uint8_t *trim_flags;  /* [n] AMP_TRIM_* bits */
+    uint8_t *status;      /* [n] amp_read_status */
+} amp_trim_out;
+
+/* Same batch with every pointer in DEVICE memory and 32-bit offsets:
+ * cig_off32[i] = cig_off[i], seq_off8[i] = seq_off[i] / 8. */
+typedef struct amp_dev_reads {
+    int64_t n_reads;
+    const int32_t *pos;
+    const uint16_t *flag;
+    const int32_t *tlen;
+    const uint32_t *lseq;
+    const uint32_t *cig_off32; /* [n+1] */
+    const uint32_t *cig;
+    const uint32_t *seq_off8;  /* [n+1] */
+    const uint8_t *seq;
+    const uint8_t *qual;
+    int64_t n_cig;             /* cig_off32[n], known to the host */
+    int64_t n_bases_padded;    /* seq_off8[n] * 8 */
+} amp_dev_reads;
+
+/* ---- library ------------------------------------------------------------------------ */
+int amp_version(void);                        /* AMP_ABI_VERSION */
+const char *amp_strerror(int rc);
+const char *amp_last_error(const amp_ctx *ctx); /* text of the last failing HIP call */
+const char *amp_read_status_exception(int status); /* "IndexError", "KeyError", ... */
+int amp_device_count(void);
+
+/* ---- primer tables: find_overlapping_primers, AmpliPy.py:174-209 (host, once per run) --
+ * primers must be sorted ascending by (start, end) like AmpliPy.py:257.  Writes -1 for
+ * None.  max_primer_len = max(end - start) (AmpliPy.py:876). */
+int amp_find_overlapping_primers(int32_t ref_len, int32_t n_primers, const int32_t *starts,
+                                 const int32_t *ends, int32_t primer_pos_offset,
+                                 int32_t *min_primer_start, int32_t *max_primer_end,
+                                 int32_t *max_primer_len);
+
+/* ---- context -------------------------------------------------------------------------- */
+/* Allocates the zeroed count table uint32[ref_len][AMP_NSYM] on `device` (AmpliPy.py:892). */
+int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len);
+void amp_ctx_destroy(amp_ctx *ctx);
+/* Optional: run all work of this ctx on the caller's HIP stream (hipStream_t). */
+int amp_ctx_set_stream(amp_ctx *ctx, void *hip_stream);
+/* Optional: use caller-owned DEVICE memory (uint32[ref_len*AMP_NSYM], e.g. a torch tensor)
+ * as the count table so torch.distributed can reduce it in place. Contents are kept. */
+int amp_ctx_bind_counts(amp_ctx *ctx, void *dev_counts);
+
+/* Tables consumed by trim_read (AmpliPy.py:450-452); host pointers, length ref_len. */
+int amp_set_primers(amp_ctx *ctx, const int32_t *min_primer_start,
+                    const int32_t *max_primer_end, int32_t max_primer_len);
+/* min_quality / sliding_window_width of AmpliPy.py:907,915; do_trim = run_trim,
+ * do_count = run_variants or run_consensus (AmpliPy.py:906, 914). */
+int amp_set_params(amp_ctx *ctx, int32_t min_quality, int32_t window, int32_t do_trim,
+                   int32_t do_count);
+
+/* ---- the hot path: AmpliPy.py:896-915 for a whole batch --------------------------------
+ * Host-pointer form: stages the batch to the device, runs the kernels, copies `out` back.
+ * read_base is added to amp_ins_event.read so events of several batches stay distinct. */
+int amp_process_batch(amp_ctx *ctx, const amp_reads *reads, uint64_t read_base,
+                      const amp_trim_out *out);
+/* Device-pointer form: inputs and outputs already resident in HBM; asynchronous on the
+ * ctx stream (outputs are valid after amp_sync). */
+int amp_process_batch_device(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base,
+                             const amp_trim_out *dev_out);
+int amp_sync(amp_ctx *ctx);
+
+/* Time spent in the kernels of the last amp_process_batch* call, measured with HIP events
+ * on the ctx stream: total, and the dominant (CIGAR-scan) kernel alone. */
+int amp_last_kernel_ms(amp_ctx *ctx, float *total_ms, float *scan_ms);
+
+/* ---- accumulated state ----------------------------------------------------------------- */
+int amp_get_counts(amp_ctx *ctx, uint32_t *counts /* [ref_len][AMP_NSYM] host */);
+int amp_add_counts(amp_ctx *ctx, const uint32_t *counts /* host, added element-wise */);
+/* *n = number of events recorded so far; copies min(*n, cap) of them when buf != NULL. */
+int amp_get_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
+void *amp_counts_device_ptr(amp_ctx *ctx);
+/* Sum count tables over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
+ * (root < 0: all ranks).  comm == NULL is a no-op (single GPU). */
+int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);
+int amp_reset(amp_ctx *ctx); /* zero the count table and drop recorded events */
+
+/* ---- calling: alleles_from_counts + AmpliPy.py:917-952, integer/double part ---------------
+ * Insertion alleles are strings, aggregated by the host into (ref_pos, count) rows sorted by
+ * ref_pos then by DESCENDING Python string order (the tie-break of AmpliPy.py:771).
+ * For every position the device returns total depth, the 6 base symbols ranked like
+ * sorted(..., reverse=True), and consensus / variant decisions (see amp_call_out). */
+typedef struct amp_call_params {
+    int32_t min_depth_consensus;
+    int32_t min_depth_variants;
+    double min_freq_consensus;
+    double min_freq_variants;
+    int32_t run_consensus;
+    int32_t run_variants;
+} amp_call_params;
+
+/* One ranked allele of one position. sym: 0..5 = A C G T N '-', 6+k = k-th insertion row of
+ * that position (in the order given). */
+typedef struct amp_allele {
+    uint32_t count;
+    int32_t sym;
+} amp_allele;
+
+typedef struct amp_call_out {
+    uint32_t *total_depth;   /* [ref_len] sum of all symbol counts incl. insertions (:767) */
+    int32_t *consensus_sym;  /* [ref_len] -1 = unknown symbol, else sym as in amp_allele (:928-929) */
+    int32_t *n_alleles;      /* [ref_len] number of non-zero alleles */
+    uint64_t *allele_off;    /* [ref_len+1] offsets into alleles */
+    amp_allele *alleles;     /* [alleles_cap] ranked alleles of every position, concatenated */
+    int64_t alleles_cap;
+    uint8_t *variant_flags;  /* [ref_len] bit0: record emitted (:940); bit1: GT includes 0 (:948) */
+    uint32_t *ref_count;     /* [ref_len] count of the reference symbol (:937) */
+    uint64_t *alt_mask;      /* [ref_len] bit r set: ranked allele r is an ALT (:938-939), r < 64 */
+} amp_call_out;
+
+int amp_call(amp_ctx *ctx, const amp_call_params *params, const uint8_t *ref_seq /* ASCII [ref_len] */,
+             int64_t n_ins, const int32_t *ins_pos, const uint32_t *ins_count,
+             const amp_call_out *out /* host pointers */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPLIHIP_H */
