@@ -83,6 +83,16 @@ class TrimResult:
         return AmpTrimOut(ptr(self.new_pos), ptr(self.new_ncig), ptr(self.new_cig), ptr(self.ref_len),
                           ptr(self.trim_flags), ptr(self.status))
 
+    def compact_cigars(self):
+        """All reads' new CIGAR words concatenated in read order (slack between slots dropped)."""
+        n = self.new_ncig.astype(np.int64)
+        start = self.batch.cig_off[:-1].astype(np.int64) + 3 * np.arange(n.size, dtype=np.int64)
+        tot = int(n.sum())
+        if tot == 0:
+            return np.zeros(0, np.uint32)
+        first = np.repeat(start - (np.cumsum(n) - n), n)
+        return self.new_cig[first + np.arange(tot, dtype=np.int64)]
+
     def cigar_ops(self, i):
         o = int(self.batch.cig_off[i]) + 3 * i
         return [(int(v) & 15, int(v) >> 4) for v in self.new_cig[o:o + int(self.new_ncig[i])]]

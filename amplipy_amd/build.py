@@ -1,0 +1,35 @@
+"""In-tree build of libamplihip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "amplihip.hip")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "amp_read.hpp"), os.path.join(_HERE, "csrc", "amp_tile.hpp"),
+        os.path.join(_HERE, "..", "include", "amplihip.h")]
+OUT = os.path.join(_HERE, "libamplihip.so")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.isfile(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", OUT, SRC, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

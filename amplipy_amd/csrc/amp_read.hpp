@@ -1,0 +1,464 @@
+// amp_read.hpp -- per-read device logic of libamplihip: CIGAR coordinate maps, primer /
+// quality soft-clipping, and the exact aligned-pair walk used for reads the tile kernel
+// does not take on its fast path.
+//
+// Every function restates behaviour of /root/reference/AmpliPy.py v0.0.2 (cited A:line);
+// none of it is a translation: the reference builds Python lists and calls fix_cigar after
+// each stage, here each stage streams ops through an emitter that merges equal neighbours
+// on the fly, works on `len<<4|op` words in LDS or global memory, and keeps all state in
+// registers.  Functions are __host__ __device__ only so that tests/hostsim can run the same
+// code on the CPU against the golden vectors; the shipped library never executes them on
+// the host.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amplihip.h"
+
+#define AMP_HD __host__ __device__ __forceinline__
+
+namespace amp {
+
+constexpr uint32_t OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8;
+
+// A:43-44 as bit sets over op codes 0..8
+AMP_HD bool consumes_query(uint32_t op) { return (0x193u >> op) & 1u; }  // M I S = X
+AMP_HD bool consumes_ref(uint32_t op) { return (0x18Du >> op) & 1u; }    // M D N = X
+AMP_HD bool is_match_op(uint32_t op) { return (0x181u >> op) & 1u; }     // M = X
+
+struct KParams {
+    int32_t min_quality, window, do_trim, do_count;
+    int32_t ref_len, max_primer_len;
+    const int32_t *min_start, *max_end;  // -1 = None; valid when do_trim
+};
+
+// Device pointers of amp_trim_out (any may be null except new_cig, which the launcher always provides).
+struct DevOut {
+    int32_t *new_pos;
+    uint32_t *new_ncig;
+    uint32_t *new_cig;
+    int32_t *ref_len;
+    uint8_t *trim_flags;
+    uint8_t *status;
+};
+
+// A CIGAR held as BAM words with element stride S (1 = contiguous global memory,
+// blockDim = one column per lane in LDS).
+template <int S>
+struct CigBuf {
+    uint32_t *p;
+    AMP_HD uint32_t get(int i) const { return p[i * S]; }
+    AMP_HD void set(int i, uint32_t v) const { p[i * S] = v; }
+};
+
+template <int S>
+AMP_HD void reverse_ops(const CigBuf<S> &b, int n) {
+    for (int i = 0, j = n - 1; i < j; ++i, --j) {
+        uint32_t t = b.get(i);
+        b.set(i, b.get(j));
+        b.set(j, t);
+    }
+}
+
+// Streams ops into a buffer, folding runs of the same op (the effect of fix_cigar, A:415-423).
+template <int S>
+struct Emitter {
+    CigBuf<S> b;
+    int n = 0;
+    uint32_t pend = 0;
+    bool has = false;
+    AMP_HD void push(uint32_t op, uint32_t len) {
+        if (has && (pend & 15u) == op) {
+            pend += len << 4;
+        } else {
+            if (has) b.set(n++, pend);
+            pend = (len << 4) | op;
+            has = true;
+        }
+    }
+    AMP_HD uint32_t last_op() const { return pend & 15u; }
+    AMP_HD int finish() {
+        if (has) b.set(n++, pend);
+        has = false;
+        return n;
+    }
+};
+
+// A:389-412 get_pos_on_query
+template <int S>
+AMP_HD int32_t pos_on_query(const CigBuf<S> &c, int n, int32_t ref_pos, int32_t ref_start, int &err) {
+    int32_t query_pos = 0, cur = ref_start;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = c.get(i), op = v & 15u;
+        int32_t len = (int32_t)(v >> 4);
+        if (op >= 9) { err = AMP_RS_CIGAR_OP; return 0; }
+        if (consumes_ref(op)) {
+            if (ref_pos <= cur + len) return consumes_query(op) ? query_pos + (ref_pos - cur) : query_pos;
+            cur += len;
+        }
+        if (consumes_query(op)) query_pos += len;
+    }
+    return query_pos;
+}
+
+// A:363-386 get_pos_on_ref
+template <int S>
+AMP_HD int32_t pos_on_ref(const CigBuf<S> &c, int n, int32_t query_pos, int32_t ref_start, int &err) {
+    int32_t cur = 0, ref_pos = ref_start;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = c.get(i), op = v & 15u;
+        int32_t len = (int32_t)(v >> 4);
+        if (op >= 9) { err = AMP_RS_CIGAR_OP; return 0; }
+        if (consumes_query(op)) {
+            if (query_pos <= cur + len) return consumes_ref(op) ? ref_pos + (query_pos - cur) : ref_pos;
+            cur += len;
+        }
+        if (consumes_ref(op)) ref_pos += len;
+    }
+    return ref_pos;
+}
+
+// pysam accessors
+template <int S>
+AMP_HD int32_t reference_length(const CigBuf<S> &c, int n) {
+    int32_t r = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = c.get(i), op = v & 15u;
+        if (op < 9 && consumes_ref(op)) r += (int32_t)(v >> 4);
+    }
+    return r ? r : 1;
+}
+template <int S>
+AMP_HD int32_t query_alignment_start(const CigBuf<S> &c, int n, int32_t lseq, int &err) {
+    int32_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = c.get(i), op = v & 15u;
+        if (op == OP_H) {
+            if (off != 0 && off != lseq) { err = AMP_RS_CLIP; return 0; }
+        } else if (op == OP_S) {
+            off += (int32_t)(v >> 4);
+        } else {
+            break;
+        }
+    }
+    return off;
+}
+template <int S>
+AMP_HD int32_t query_alignment_end(const CigBuf<S> &c, int n, int32_t lseq, int &err) {
+    int32_t end = lseq;
+    if (end == 0) {
+        for (int i = 0; i < n; ++i) {
+            uint32_t v = c.get(i), op = v & 15u;
+            if (op == OP_M || op == OP_I || op == OP_EQ || op == OP_X || (op == OP_S && end == 0)) end += (int32_t)(v >> 4);
+        }
+        return end;
+    }
+    for (int k = n - 1; k >= 1; --k) {  // element 0 is never examined
+        uint32_t v = c.get(k), op = v & 15u;
+        if (op == OP_H) {
+            if (end != lseq) { err = AMP_RS_CLIP; return 0; }
+        } else if (op == OP_S) {
+            end -= (int32_t)(v >> 4);
+        } else {
+            break;
+        }
+    }
+    return end;
+}
+// Python slice bounds of seq[a:b] for a sequence of length L
+AMP_HD void py_slice(int32_t a, int32_t b, int32_t L, int32_t &lo, int32_t &hi) {
+    if (a < 0) { a += L; if (a < 0) a = 0; } else if (a > L) a = L;
+    if (b < 0) { b += L; if (b < 0) b = 0; } else if (b > L) b = L;
+    if (b < a) b = a;
+    lo = a; hi = b;
+}
+
+// Primer clip from the front of `src` (A:467-510; the end clip A:524-555 runs it over the
+// reversed CIGAR without position tracking).  Returns the reference advance.
+template <int S, bool TRACK>
+AMP_HD int32_t primer_clip(const CigBuf<S> &src, int n, bool reversed, int32_t del, Emitter<S> &e, int &err) {
+    bool pos_start = false;
+    int32_t start_pos = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = src.get(reversed ? n - 1 - i : i), op = v & 15u;
+        int32_t len = (int32_t)(v >> 4);
+        if (del == 0 && pos_start) { e.push(op, len); continue; }
+        if (op >= 9) { err = AMP_RS_CIGAR_OP; return 0; }
+        if (del == 0 && consumes_query(op) && consumes_ref(op)) { pos_start = true; e.push(op, len); continue; }
+        int32_t ref_add = 0;
+        if (consumes_query(op)) {
+            if (del >= len) e.push(OP_S, len);
+            else if (del > 0) e.push(OP_S, del);
+            else { e.push(OP_S, len); continue; }
+            ref_add = del < len ? del : len;
+            int32_t rest = len - del > 0 ? len - del : 0;
+            del = del - len > 0 ? del - len : 0;
+            if (rest > 0) e.push(op, rest);
+            uint32_t last = e.last_op();
+            if (del == 0 && consumes_query(last) && consumes_ref(last)) pos_start = true;
+        } else if (consumes_ref(op)) {
+            ref_add = len;
+        }
+        if (TRACK && consumes_ref(op)) start_pos += ref_add;
+    }
+    return start_pos;
+}
+
+// Quality clip from the front of `src` (A:597-622; A:658-683 over the reversed CIGAR).
+template <int S>
+AMP_HD void quality_clip(const CigBuf<S> &src, int n, bool reversed, int32_t del, Emitter<S> &e, int &err) {
+    for (int i = 0; i < n; ++i) {
+        uint32_t v = src.get(reversed ? n - 1 - i : i), op = v & 15u;
+        int32_t len = (int32_t)(v >> 4);
+        if (del == 0 || op == OP_S || op == OP_H) { e.push(op, len); continue; }
+        if (op >= 9) { err = AMP_RS_CIGAR_OP; return; }
+        if (consumes_query(op)) {
+            e.push(OP_S, del >= len ? len : del);
+            int32_t rest = len - del > 0 ? len - del : 0;
+            del = del - len > 0 ? del - len : 0;
+            if (rest > 0) e.push(op, rest);
+        }
+    }
+}
+
+// First index (from the 3' side) at which the sliding-window mean drops below min_quality:
+// A:566-587 (reverse strand, returns i = number of leading bases to clip) and A:630-649
+// (forward strand, returns i = number of leading bases kept).  total/window < q is evaluated
+// as total < q*window, which is exact for integers.
+AMP_HD int32_t quality_scan(const uint8_t *q, int32_t qlen, int32_t width, int32_t min_quality, bool reverse) {
+    int64_t total = 0, mq = min_quality;
+    int32_t window = width < qlen ? width : qlen;
+    if (reverse) {
+        int32_t i = qlen;
+        for (int32_t off = 1; off < window; ++off) total += q[i - off];
+        while (i > 0) {
+            if (window > i) window -= 1; else total += q[i - window];
+            if (total < mq * window) break;
+            total -= q[i - 1];
+            i -= 1;
+        }
+        return i;
+    }
+    int32_t i = 0;
+    for (int32_t off = 0; off < window - 1; ++off) total += q[off];
+    while (i < qlen) {
+        if (qlen - window < i) window -= 1; else total += q[i + window - 1];
+        if (total < mq * window) break;
+        total -= q[i];
+        i += 1;
+    }
+    return i;
+}
+
+struct TrimState {
+    int32_t pos;      // reference_start (updated by the start clip, A:514)
+    int n;            // ops in `cur`
+    uint32_t flags;   // AMP_TRIM_* bits
+    int err;          // amp_read_status
+};
+
+// Stage 1+2 of trim_read: primer clips (A:450-558).  `cur` holds the CIGAR, `tmp` is scratch
+// of the same capacity (n + 3); on return `cur` is the buffer holding the result.
+template <int S>
+AMP_HD void trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
+                         CigBuf<S> &cur, CigBuf<S> &tmp) {
+    const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
+    const int32_t rs = st.pos;
+    if ((uint32_t)rs >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }       // A:450
+    const int32_t re1 = rs + reference_length(cur, st.n) - 1;
+    if ((uint32_t)re1 >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }      // A:451
+    const int32_t left_max_end = P.max_end[rs];
+    const int32_t right_min_start = P.min_start[re1];
+    const int32_t at = tlen < 0 ? -tlen : tlen;
+    const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;              // A:452
+    if (!(is_paired && isize_flag && is_reverse) && left_max_end >= 0) {                   // A:460
+        st.flags |= AMP_TRIM_PRIMER_START;
+        int32_t del = pos_on_query(cur, st.n, left_max_end + 1, st.pos, st.err);           // A:463
+        if (st.err) return;
+        Emitter<S> e{tmp};
+        int32_t adv = primer_clip<S, true>(cur, st.n, false, del, e, st.err);
+        if (st.err) return;
+        st.n = e.finish();
+        st.pos += adv;                                                                     // A:514
+        CigBuf<S> t = cur; cur = tmp; tmp = t;
+    }
+    if (!(is_paired && isize_flag && !is_reverse) && right_min_start >= 0) {               // A:517
+        st.flags |= AMP_TRIM_PRIMER_END;
+        int32_t del = lseq - pos_on_query(cur, st.n, right_min_start, st.pos, st.err);     // A:520
+        if (st.err) return;
+        Emitter<S> e{tmp};
+        primer_clip<S, false>(cur, st.n, true, del, e, st.err);
+        if (st.err) return;
+        st.n = e.finish();
+        reverse_ops(tmp, st.n);                                                            // A:558
+        CigBuf<S> t = cur; cur = tmp; tmp = t;
+    }
+}
+
+// Stage 3 of trim_read given the scan result `i` of quality_scan (A:589-625, A:651-686).
+template <int S>
+AMP_HD void trim_quality_apply(TrimState &st, bool is_reverse, int32_t i, int32_t qlen, int32_t qs,
+                               CigBuf<S> &cur, CigBuf<S> &tmp) {
+    if (is_reverse) {
+        const int32_t del = i;
+        int32_t start_pos = pos_on_ref(cur, st.n, del + qs - 1, st.pos, st.err);           // A:591
+        if (st.err) return;
+        if (start_pos > st.pos) {                                                          // A:594
+            st.flags |= AMP_TRIM_QUALITY;
+            Emitter<S> e{tmp};
+            quality_clip(cur, st.n, false, del, e, st.err);
+            if (st.err) return;
+            st.n = e.finish();                              // reference_start is NOT advanced
+            CigBuf<S> t = cur; cur = tmp; tmp = t;
+        }
+    } else {
+        const int32_t del = qlen - i;
+        (void)pos_on_ref(cur, st.n, del, st.pos, st.err);                                  // A:653 (may raise)
+        if (st.err) return;
+        if (del != 0) {                                                                    // A:656
+            st.flags |= AMP_TRIM_QUALITY;
+            Emitter<S> e{tmp};
+            quality_clip(cur, st.n, true, del, e, st.err);
+            if (st.err) return;
+            st.n = e.finish();
+            reverse_ops(tmp, st.n);                                                        // A:686
+            CigBuf<S> t = cur; cur = tmp; tmp = t;
+        }
+    }
+}
+
+// Aligned-quality window [lo, lo+qlen) of A:561 for the current CIGAR; sets err like the
+// pysam accessors do.  Returns false when the read cannot be quality-trimmed.
+template <int S>
+AMP_HD bool quality_window(TrimState &st, int32_t lseq, bool have_qual, const CigBuf<S> &cur,
+                           int32_t &qs, int32_t &lo, int32_t &qlen) {
+    if (lseq == 0) { st.err = AMP_RS_NO_QUAL; return false; }
+    qs = query_alignment_start(cur, st.n, lseq, st.err);
+    if (st.err) return false;
+    int32_t qe = query_alignment_end(cur, st.n, lseq, st.err);
+    if (st.err) return false;
+    if (!have_qual) { st.err = AMP_RS_NO_QUAL; return false; }
+    int32_t hi;
+    py_slice(qs, qe, lseq, lo, hi);
+    qlen = hi - lo;
+    return true;
+}
+
+// Whole trim_read (A:426-687) for one read, scanning qualities serially.
+template <int S>
+AMP_HD void trim_read_serial(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
+                             const uint8_t *qual, bool have_qual, CigBuf<S> &cur, CigBuf<S> &tmp) {
+    trim_primers(P, st, flag, tlen, lseq, cur, tmp);
+    if (st.err) return;
+    int32_t qs, lo, qlen;
+    if (!quality_window(st, lseq, have_qual, cur, qs, lo, qlen)) return;
+    const bool rev = (flag & 0x10u) != 0;
+    int32_t i = quality_scan(qual + lo, qlen, P.window, P.min_quality, rev);
+    trim_quality_apply(st, rev, i, qlen, qs, cur, tmp);
+}
+
+// BAM 4-bit code -> count-table column; 0xFF = KeyError (A:892 has keys A C G T N '-')
+AMP_HD uint32_t code_to_col(uint32_t code) {
+    // codes 1,2,4,8,15 -> 0,1,2,3,4
+    return code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : code == 8 ? 3u : code == 15 ? 4u : 0xFFu;
+}
+AMP_HD uint32_t base_code(const uint8_t *seq, int64_t base_off, int32_t q) {
+    int64_t k = base_off + q;
+    uint32_t b = seq[k >> 1];
+    return (k & 1) ? (b & 15u) : (b >> 4);
+}
+
+// Iterator over get_aligned_pairs() without materialising the list.
+template <int S>
+struct PairIter {
+    CigBuf<S> c;
+    int n, k;
+    int32_t j, len, q, r;
+    uint32_t op;
+    AMP_HD void init(const CigBuf<S> &cig, int nops, int32_t ref_start) {
+        c = cig; n = nops; k = -1; j = 0; len = 0; q = 0; r = ref_start; op = OP_H;
+    }
+    // fetches the next pair; pq/pr = -1 for None
+    AMP_HD bool next(int32_t &pq, int32_t &pr) {
+        while (j >= len) {
+            if (++k >= n) return false;
+            uint32_t v = c.get(k);
+            op = v & 15u; j = 0;
+            len = (op == OP_H || op >= 9) ? 0 : (int32_t)(v >> 4);
+        }
+        ++j;
+        if (is_match_op(op)) { pq = q++; pr = r++; }
+        else if (op == OP_D || op == OP_N) { pq = -1; pr = r++; }
+        else { pq = q++; pr = -1; }  // I, S and (pysam quirk) P
+        return true;
+    }
+};
+
+// update_base_counts (A:690-753) for one read as an exact sequential walk.  Sink provides
+//   void add(int32_t ref_pos, uint32_t col)   and   void event(int32_t ref_pos, int32_t from, int32_t to)
+template <int S, class Sink>
+AMP_HD int count_read_walk(const KParams &P, const CigBuf<S> &cig, int n, int32_t ref_start, int32_t lseq,
+                           const uint8_t *seq, int64_t base_off, const uint8_t *qual, bool have_qual, Sink &sink) {
+    int err = 0;
+    const int32_t qs = query_alignment_start(cig, n, lseq, err);                           // A:700
+    if (err) return err;
+    const int32_t qe = query_alignment_end(cig, n, lseq, err);                             // A:701
+    if (err) return err;
+    if (lseq == 0) return AMP_RS_NO_SEQ;                                                   // A:702
+    const int32_t ref_end = ref_start + reference_length(cig, n);                          // A:705
+    const uint32_t G = (uint32_t)P.ref_len;
+    const int32_t mq = P.min_quality;
+    PairIter<S> it;
+    it.init(cig, n, ref_start);
+    int32_t q, r;
+    bool pending = false;  // a pair fetched by the insertion scan and handed back (A:743)
+    int32_t pend_q = 0, pend_r = 0;
+    for (;;) {
+        if (pending) { q = pend_q; r = pend_r; pending = false; }
+        else if (!it.next(q, r)) break;
+        if (q < 0) {                                                                       // A:714-715
+            if ((uint32_t)r >= G) return AMP_RS_INDEX_REF;
+            sink.add(r, 5u);
+            continue;
+        }
+        if (!have_qual) return AMP_RS_NO_QUAL;
+        if (q >= lseq) return AMP_RS_INDEX_QUERY;
+        if ((int32_t)qual[q] < mq) continue;                                               // A:718
+        if (q < qs) continue;                                                              // A:722
+        if (q >= qe) break;                                                                // A:726
+        if (r < 0) {                                                                       // A:730-748
+            const int32_t q0 = q;
+            bool q_none = false;
+            while (r < 0 && !q_none && q < qe) {
+                if (q >= lseq) return AMP_RS_INDEX_QUERY;
+                if ((int32_t)qual[q] < mq) break;
+                if (!it.next(q, r)) return AMP_RS_INDEX_PAIRS;                             // A:734
+                if (q < 0) q_none = true;
+            }
+            int32_t lo, hi;
+            if (r == 0) {                                                                  // A:735-736
+                if (q_none) return AMP_RS_TYPE;
+                py_slice(q0, q + 1, lseq, lo, hi);
+            } else if (q_none) {
+                py_slice(q0 - 1, lseq, lseq, lo, hi);                                      // seq[a:None]
+            } else {
+                py_slice(q0 - 1, q, lseq, lo, hi);                                         // A:738
+            }
+            int32_t ins_pos;
+            if (r < 0) ins_pos = ref_end;                                                  // A:739-740
+            else { ins_pos = r; pending = true; pend_q = q; pend_r = r; }                  // A:742-743
+            ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                                   // A:744
+            if ((uint32_t)ins_pos >= G) return AMP_RS_INDEX_REF;
+            sink.event(ins_pos, lo, hi);
+            continue;
+        }
+        if ((uint32_t)r >= G) return AMP_RS_INDEX_REF;                                     // A:751-753
+        const uint32_t col = code_to_col(base_code(seq, base_off, q));
+        if (col == 0xFFu) return AMP_RS_KEY_BASE;
+        sink.add(r, col);
+    }
+    return 0;
+}
+
+}  // namespace amp

@@ -1,0 +1,218 @@
+"""ctypes binding of libamplihip.so (include/amplihip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``amplipy_amd.build``.  There is
+no Python or CPU fallback: if the shared object is missing or no GPU is visible, the calls
+below raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamplihip.so")
+_LIB = None
+
+EXPORTS = [
+    "amp_version", "amp_strerror", "amp_last_error", "amp_read_status_exception", "amp_device_count",
+    "amp_find_overlapping_primers", "amp_ctx_create", "amp_ctx_destroy", "amp_ctx_set_stream",
+    "amp_ctx_bind_counts", "amp_set_primers", "amp_set_params", "amp_process_batch",
+    "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
+    "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
+    "amp_reserve_events", "amp_set_kernel_variant", "amp_call",
+]
+
+
+class AmpliHipError(RuntimeError):
+    def __init__(self, rc, where, detail=""):
+        self.rc = rc
+        super().__init__("%s: %s (%d)%s" % (where, abi.RC_NAMES.get(rc, "?"), rc, (": " + detail) if detail else ""))
+
+
+def load():
+    """Load libamplihip.so or raise -- never substitutes anything else."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); amplipy_amd has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(L, name)  # AttributeError if the build is stale
+        L.amp_strerror.restype = C.c_char_p
+        L.amp_last_error.restype = C.c_char_p
+        L.amp_last_error.argtypes = [C.c_void_p]
+        L.amp_read_status_exception.restype = C.c_char_p
+        L.amp_counts_device_ptr.restype = C.c_void_p
+        L.amp_counts_device_ptr.argtypes = [C.c_void_p]
+        L.amp_ctx_destroy.restype = None
+        L.amp_ctx_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def find_overlapping_primers(ref_len, primers, offset):
+    """find_overlapping_primers (AmpliPy.py:174-209) -> (min_start, max_end, max_primer_len);
+    -1 stands for None."""
+    L = load()
+    ps = sorted((int(a), int(b)) for a, b in primers)
+    st = np.array([p[0] for p in ps], np.int32); en = np.array([p[1] for p in ps], np.int32)
+    mn = np.empty(ref_len, np.int32); mx = np.empty(ref_len, np.int32)
+    mpl = C.c_int32(0)
+    rc = L.amp_find_overlapping_primers(C.c_int32(ref_len), C.c_int32(len(ps)), C.c_void_p(abi.ptr(st)),
+                                        C.c_void_p(abi.ptr(en)), C.c_int32(offset), C.c_void_p(abi.ptr(mn)),
+                                        C.c_void_p(abi.ptr(mx)), C.byref(mpl))
+    if rc:
+        raise AmpliHipError(rc, "amp_find_overlapping_primers")
+    return mn, mx, int(mpl.value)
+
+
+class Engine:
+    """One amp_ctx: the device-side state of a run (count table, insertion events)."""
+
+    def __init__(self, ref_len, device=0):
+        self.L = load()
+        self.ref_len = int(ref_len)
+        self.device = device
+        h = C.c_void_p()
+        rc = self.L.amp_ctx_create(C.byref(h), C.c_int(device), C.c_int32(ref_len))
+        if rc:
+            raise AmpliHipError(rc, "amp_ctx_create", "no usable MI355X device" if rc == -4 else "")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc:
+            raise AmpliHipError(rc, where, (self.L.amp_last_error(self.h) or b"").decode())
+
+    # ---- configuration ---------------------------------------------------------------
+    def set_primers(self, min_start, max_end, max_primer_len):
+        mn = np.ascontiguousarray(min_start, np.int32); mx = np.ascontiguousarray(max_end, np.int32)
+        assert mn.size == self.ref_len and mx.size == self.ref_len
+        self._chk(self.L.amp_set_primers(self.h, C.c_void_p(abi.ptr(mn)), C.c_void_p(abi.ptr(mx)),
+                                         C.c_int32(max_primer_len)), "amp_set_primers")
+
+    def set_params(self, min_quality=20, window=4, do_trim=True, do_count=True):
+        self._chk(self.L.amp_set_params(self.h, C.c_int32(min_quality), C.c_int32(window), C.c_int32(int(do_trim)),
+                                        C.c_int32(int(do_count))), "amp_set_params")
+
+    def set_kernel_variant(self, v):
+        self._chk(self.L.amp_set_kernel_variant(self.h, C.c_int(v)), "amp_set_kernel_variant")
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.amp_ctx_set_stream(self.h, C.c_void_p(hip_stream)), "amp_ctx_set_stream")
+
+    def bind_counts(self, dev_ptr):
+        self._chk(self.L.amp_ctx_bind_counts(self.h, C.c_void_p(dev_ptr)), "amp_ctx_bind_counts")
+
+    def reserve_events(self, cap):
+        self._chk(self.L.amp_reserve_events(self.h, C.c_int64(cap)), "amp_reserve_events")
+
+    # ---- hot path --------------------------------------------------------------------
+    def process(self, batch, read_base=0, want_trim=True):
+        """amp_process_batch on a host ReadBatch; returns abi.TrimResult."""
+        res = abi.TrimResult(batch)
+        rd = abi.reads_struct(batch)
+        out = res.struct()
+        self._chk(self.L.amp_process_batch(self.h, C.byref(rd), C.c_uint64(read_base),
+                                           C.byref(out) if want_trim else None), "amp_process_batch")
+        return res
+
+    def process_device(self, dev_reads, read_base=0, dev_out=None):
+        """amp_process_batch_device: abi.AmpDevReads of device pointers; asynchronous."""
+        self._chk(self.L.amp_process_batch_device(self.h, C.byref(dev_reads), C.c_uint64(read_base),
+                                                  C.byref(dev_out) if dev_out is not None else None),
+                  "amp_process_batch_device")
+
+    def sync(self):
+        self._chk(self.L.amp_sync(self.h), "amp_sync")
+
+    def last_kernel_ms(self):
+        t = C.c_float(0); s = C.c_float(0)
+        self._chk(self.L.amp_last_kernel_ms(self.h, C.byref(t), C.byref(s)), "amp_last_kernel_ms")
+        return float(t.value), float(s.value)
+
+    # ---- state -----------------------------------------------------------------------
+    def counts(self):
+        c = np.empty((self.ref_len, abi.NSYM), np.uint32)
+        self._chk(self.L.amp_get_counts(self.h, C.c_void_p(abi.ptr(c))), "amp_get_counts")
+        return c
+
+    def add_counts(self, counts):
+        c = np.ascontiguousarray(counts, np.uint32)
+        assert c.size == self.ref_len * abi.NSYM
+        self._chk(self.L.amp_add_counts(self.h, C.c_void_p(abi.ptr(c))), "amp_add_counts")
+
+    def counts_device_ptr(self):
+        return self.L.amp_counts_device_ptr(self.h)
+
+    def events(self):
+        n = C.c_int64(0)
+        self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), None, C.c_int64(0)), "amp_get_ins_events")
+        ev = np.zeros(int(n.value), abi.INS_EVENT_DTYPE)
+        if n.value:
+            self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)),
+                      "amp_get_ins_events")
+        return ev
+
+    def error_reads(self):
+        n = C.c_int64(0)
+        self._chk(self.L.amp_error_reads(self.h, C.byref(n)), "amp_error_reads")
+        return int(n.value)
+
+    def reduce(self, comm=None, root=0):
+        self._chk(self.L.amp_reduce(self.h, C.c_void_p(comm), C.c_int(root)), "amp_reduce")
+
+    def reset(self):
+        self._chk(self.L.amp_reset(self.h), "amp_reset")
+
+    # ---- calling ---------------------------------------------------------------------
+    def call(self, params, ref_seq, ins_rows):
+        """amp_call.  ``ins_rows`` = [(ref_pos, string, count)] sorted by ref_pos then by string
+        DESCENDING.  Returns a dict of numpy arrays (see amp_call_out)."""
+        G = self.ref_len
+        n = len(ins_rows)
+        ipos = np.array([r[0] for r in ins_rows], np.int32)
+        icnt = np.array([r[2] for r in ins_rows], np.uint32)
+        strs = [r[1].encode("ascii") for r in ins_rows]
+        ilen = np.array([len(s) for s in strs], np.int32)
+        sarr = (C.c_char_p * max(n, 1))(*strs) if n else (C.c_char_p * 1)()
+        cap = G * abi.NSYM + n
+        out = {
+            "total_depth": np.zeros(G, np.uint32), "consensus_sym": np.zeros(G, np.int32),
+            "n_alleles": np.zeros(G, np.int32), "allele_off": np.zeros(G + 1, np.uint64),
+            "alleles": np.zeros(cap, np.dtype([("count", "<u4"), ("sym", "<i4")])),
+            "variant_flags": np.zeros(G, np.uint8), "ref_count": np.zeros(G, np.uint32),
+            "allele_flags": np.zeros(cap, np.uint8),
+        }
+
+        class CallOut(C.Structure):
+            _fields_ = [("total_depth", C.c_void_p), ("consensus_sym", C.c_void_p), ("n_alleles", C.c_void_p),
+                        ("allele_off", C.c_void_p), ("alleles", C.c_void_p), ("alleles_cap", C.c_int64),
+                        ("variant_flags", C.c_void_p), ("ref_count", C.c_void_p), ("allele_flags", C.c_void_p)]
+
+        co = CallOut(abi.ptr(out["total_depth"]), abi.ptr(out["consensus_sym"]), abi.ptr(out["n_alleles"]),
+                     abi.ptr(out["allele_off"]), abi.ptr(out["alleles"]), cap, abi.ptr(out["variant_flags"]),
+                     abi.ptr(out["ref_count"]), abi.ptr(out["allele_flags"]))
+        ref = np.frombuffer(ref_seq.encode("ascii") if isinstance(ref_seq, str) else bytes(ref_seq), np.uint8)
+        assert ref.size == G
+        self._chk(self.L.amp_call(self.h, C.byref(params), C.c_void_p(abi.ptr(ref)), C.c_int64(n),
+                                  C.c_void_p(abi.ptr(ipos)) if n else None, C.c_void_p(abi.ptr(icnt)) if n else None,
+                                  sarr if n else None, C.c_void_p(abi.ptr(ilen)) if n else None, C.byref(co)),
+                  "amp_call")
+        return out

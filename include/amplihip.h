@@ -192,6 +192,15 @@ void *amp_counts_device_ptr(amp_ctx *ctx);
  * (root < 0: all ranks).  comm == NULL is a no-op (single GPU). */
 int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);
 int amp_reset(amp_ctx *ctx); /* zero the count table and drop recorded events */
+/* Number of reads with a non-zero amp_read_status since the last amp_reset. */
+int amp_error_reads(amp_ctx *ctx, int64_t *n);
+/* Pre-size the insertion-event buffer.  Without it every amp_process_batch* call first runs
+ * a small bound kernel and synchronises to size the buffer; with it the call is fully
+ * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short. */
+int amp_reserve_events(amp_ctx *ctx, int64_t cap);
+/* 2 (default) = tile kernel; 1 = one-lane-per-read kernels, kept for on-GPU A/B checks.
+ * Also settable with the environment variable AMPLIHIP_KERNEL. */
+int amp_set_kernel_variant(amp_ctx *ctx, int variant);
 
 /* ---- calling: alleles_from_counts + AmpliPy.py:917-952, integer/double part ---------------
  * Insertion alleles are strings, aggregated by the host into (ref_pos, count) rows sorted by
@@ -223,11 +232,12 @@ typedef struct amp_call_out {
     int64_t alleles_cap;
     uint8_t *variant_flags;  /* [ref_len] bit0: record emitted (:940); bit1: GT includes 0 (:948) */
     uint32_t *ref_count;     /* [ref_len] count of the reference symbol (:937) */
-    uint64_t *alt_mask;      /* [ref_len] bit r set: ranked allele r is an ALT (:938-939), r < 64 */
+    uint8_t *allele_flags;   /* [alleles_cap] parallel to alleles: 1 = ALT (:938-939), 2 = the REF symbol (:936) */
 } amp_call_out;
 
 int amp_call(amp_ctx *ctx, const amp_call_params *params, const uint8_t *ref_seq /* ASCII [ref_len] */,
              int64_t n_ins, const int32_t *ins_pos, const uint32_t *ins_count,
+             const uint8_t *const *ins_str, const int32_t *ins_len,
              const amp_call_out *out /* host pointers */);
 
 #ifdef __cplusplus

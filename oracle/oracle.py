@@ -84,7 +84,7 @@ class OracleResult:
 
 
 def process(batch, ref_len, min_start=None, max_end=None, max_primer_len=0, min_quality=20, window=4,
-            do_trim=True, do_count=True, counts=None, lo=0, hi=None, read_base=0):
+            do_trim=True, do_count=True, counts=None, lo=0, hi=None, read_base=0, _fn=None, _free=None):
     """Run rows [lo, hi) of ``batch`` through the restatement (A:896-915)."""
     hi = batch.n if hi is None else hi
     res = abi.TrimResult(batch)
@@ -95,7 +95,8 @@ def process(batch, ref_len, min_start=None, max_end=None, max_primer_len=0, min_
     min_start = np.ascontiguousarray(min_start, np.int32); max_end = np.ascontiguousarray(max_end, np.int32)
     rd = abi.reads_struct(batch); out = res.struct()
     evp = C.c_void_p(); nev = C.c_int64(0)
-    rc = lib().orc_process_range(C.c_int32(min_quality), C.c_int32(window), C.c_int32(int(do_trim)),
+    fn = _fn if _fn is not None else lib().orc_process_range
+    rc = fn(C.c_int32(min_quality), C.c_int32(window), C.c_int32(int(do_trim)),
                                  C.c_int32(int(do_count)), C.c_int32(ref_len), C.c_void_p(abi.ptr(min_start)),
                                  C.c_void_p(abi.ptr(max_end)), C.c_int32(max_primer_len), C.byref(rd),
                                  C.c_int64(lo), C.c_int64(hi), C.c_uint64(read_base), C.byref(out),
@@ -109,7 +110,7 @@ def process(batch, ref_len, min_start=None, max_end=None, max_primer_len=0, min_
     else:
         events = np.zeros(0, abi.INS_EVENT_DTYPE)
     if evp.value:
-        lib().orc_free(evp)
+        (_free if _free is not None else lib().orc_free)(evp)
     return OracleResult(res, counts, events)
 
 

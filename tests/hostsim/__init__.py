@@ -1,0 +1,29 @@
+"""Loader for the CPU simulation of the device per-read functions (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+from oracle import oracle
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libhostsim.so")
+        src = os.path.join(_HERE, "hostsim.hip")
+        hdr = os.path.join(_HERE, "..", "..", "amplipy_amd", "csrc", "amp_read.hpp")
+        if not os.path.isfile(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["hipcc", "-O1", "-fPIC", "-shared", "--offload-arch=gfx950", "-o", so, src])
+        _LIB = C.CDLL(so)
+        _LIB.sim_process_range.restype = C.c_int
+        _LIB.sim_free.restype = None
+    return _LIB
+
+
+def process(batch, ref_len, mn, mx, mpl, mq, w, do_trim=True, do_count=True, **kw):
+    L = lib()
+    return oracle.process(batch, ref_len, mn, mx, mpl, mq, w, do_trim=do_trim, do_count=do_count,
+                          _fn=L.sim_process_range, _free=L.sim_free, **kw)

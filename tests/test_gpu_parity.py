@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C ABI) with the reference-derived golden vectors and
+with the CPU oracle.  Integer / index work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from amplipy_amd import synth
+from amplipy_amd.batch import ReadBatch
+from oracle import oracle
+from tests import helpers as H
+from tests.gpu_util import GpuRunner, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[1, 2], ids=["lane_kernel", "tile_kernel"])
+def runner(request):
+    r = GpuRunner(variant=request.param)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def scheme():
+    g = synth.make_genome()
+    primers, amps = synth.make_artic_scheme()
+    pr = [(s, e) for s, e, _ in primers]
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, 0)
+    return g, pr, amps, mn, mx, mpl
+
+
+@pytest.mark.parametrize("fixture", ["named_cases.json", "random_reads.json.gz"])
+def test_golden_per_read(runner, fixture):
+    def fn(b, G, mn, mx, mpl, mq, w, do_trim):
+        return runner.process(b, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+    fails = []
+    for case in H.load_json(fixture)["cases"]:
+        fails += H.check_case_with(fn, case, oracle.find_overlapping_primers)
+    assert not fails, "\n".join(fails[:40])
+
+
+def test_golden_pileup_batch(runner):
+    g = H.load_json("pileup_5000.json.gz")
+    b = ReadBatch.from_segments([H.seg_from_dict(d) for d in g["reads"]])
+    mn, mx, mpl = oracle.find_overlapping_primers(g["ref_len"], g["primers"], g["offset"])
+    r = runner.process(b, g["ref_len"], mn, mx, mpl, g["params"]["min_quality"], g["params"]["window"])
+    assert not r.trim.status.any()
+    for i, (pos, cig, flags, reflen) in enumerate(g["trim"]):
+        assert (int(r.trim.new_pos[i]), r.trim.cigar_string(i), int(r.trim.ref_len[i])) == (pos, cig, reflen), i
+        assert [bool(r.trim.trim_flags[i] & m) for m in (1, 2, 4)] == flags
+    assert H.sparse_from_engine(r.counts, b, r.events) == H.sparse_from_golden(g["counts"])
+
+
+@pytest.mark.parametrize("seed,mq,w,off", [(1, 20, 4, 0), (2, 0, 1, 1), (3, 30, 9, 2), (4, 25, 200, 0), (5, 20, 4, 5)])
+def test_random_reads_vs_oracle(runner, seed, mq, w, off):
+    g = synth.make_genome()
+    primers, _ = synth.make_artic_scheme()
+    pr = [(s, e) for s, e, _ in primers]
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, off)
+    rng = np.random.default_rng(seed)
+    segs = synth.random_segments(rng, 6000, g.size, pr)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, g.size, mn, mx, mpl, mq, w)
+    d = runner.process(b, g.size, mn, mx, mpl, mq, w)
+    assert_same(a, d, b, check_counts=False)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    for do_trim in (True, False):
+        a = oracle.process(good, g.size, mn, mx, mpl, mq, w, do_trim=do_trim)
+        bad = a.trim.status != 0
+        if bad.any():  # reads that only fail when counted untrimmed
+            good2 = ReadBatch.from_segments([segs[ok[i]] for i in np.nonzero(~bad)[0]])
+            a = oracle.process(good2, g.size, mn, mx, mpl, mq, w, do_trim=do_trim)
+            d = runner.process(good2, g.size, mn, mx, mpl, mq, w, do_trim=do_trim)
+            assert_same(a, d, good2)
+        else:
+            d = runner.process(good, g.size, mn, mx, mpl, mq, w, do_trim=do_trim)
+            assert_same(a, d, good)
+
+
+def test_config2_1k_depth(runner, scheme):
+    """BASELINE config 2: 29.9 kb genome, 150 bp reads at 1k x (199,353 reads)."""
+    g, pr, amps, mn, mx, mpl = scheme
+    b = synth.make_amplicon_batch(g, amps, synth.reads_for_depth(1000), seed=1)
+    a = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+    d = runner.process(b, g.size, mn, mx, mpl, 20, 4)
+    assert_same(a, d, b)
+
+
+def test_config5_mixed_pool(runner, scheme):
+    """BASELINE config 5 shapes: 75-300 bp, long soft clips, indel-heavy CIGARs."""
+    g, pr, amps, mn, mx, mpl = scheme
+    segs = synth.make_mixed_segments(g, amps, 20000, seed=3)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+    d = runner.process(b, g.size, mn, mx, mpl, 20, 4)
+    assert_same(a, d, b)
+
+
+def test_empty_and_tiny_batches(runner, scheme):
+    g, pr, amps, mn, mx, mpl = scheme
+    empty = ReadBatch.from_segments([])
+    d = runner.process(empty, g.size, mn, mx, mpl)
+    assert d.counts.sum() == 0 and d.events.size == 0
+    b = synth.make_amplicon_batch(g, amps, 1, seed=9)
+    assert_same(oracle.process(b, g.size, mn, mx, mpl), runner.process(b, g.size, mn, mx, mpl), b)
+    b = synth.make_amplicon_batch(g, amps, 65, seed=10)
+    assert_same(oracle.process(b, g.size, mn, mx, mpl), runner.process(b, g.size, mn, mx, mpl), b)
+
+
+def test_sharding_is_exact(runner, scheme):
+    """Counts are integer sums over reads: any partition of the batch gives the same table."""
+    g, pr, amps, mn, mx, mpl = scheme
+    b = synth.make_amplicon_batch(g, amps, 50000, seed=11)
+    whole = runner.process(b, g.size, mn, mx, mpl)
+    e = runner.engine(g.size)
+    e.reset()
+    cuts = [0, 7, 12345, 12346, 40000, b.n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        e.process(b.slice(lo, hi), read_base=lo)
+    assert np.array_equal(e.counts(), whole.counts)
+    from tests.gpu_util import EV_ORDER
+    assert np.array_equal(np.sort(e.events(), order=EV_ORDER), np.sort(whole.events, order=EV_ORDER))
+
+
+def test_replication_property_full_depth(runner, scheme):
+    """Size-independent check at BASELINE's 100k x size: a batch repeated k times must give
+    exactly k times the counts of one copy (which is itself checked against the oracle)."""
+    g, pr, amps, mn, mx, mpl = scheme
+    base = synth.make_amplicon_batch(g, amps, synth.reads_for_depth(1000), seed=2)
+    a = oracle.process(base, g.size, mn, mx, mpl)
+    e = runner.engine(g.size)
+    e.reset(); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
+    k = 100 if runner.variant == 2 else 10
+    for rep in range(k):
+        e.process(base, read_base=0, want_trim=False)
+    assert np.array_equal(e.counts(), a.counts * np.uint32(k))
+    assert e.events().size == a.events.size * k
