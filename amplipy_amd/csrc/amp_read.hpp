@@ -43,8 +43,9 @@ struct DevOut {
     uint8_t *status;
 };
 
-// A CIGAR held as BAM words with element stride S (1 = contiguous global memory,
-// blockDim = one column per lane in LDS).
+// A CIGAR held as BAM words.  Every function below is generic over the buffer class CB, which
+// provides get(i) / set(i, v) and a pointer member p: CigBuf<1> is contiguous global memory;
+// the tile kernel uses an LDS-address-space buffer with one column per lane.
 template <int S>
 struct CigBuf {
     uint32_t *p;
@@ -52,8 +53,8 @@ struct CigBuf {
     AMP_HD void set(int i, uint32_t v) const { p[i * S] = v; }
 };
 
-template <int S>
-AMP_HD void reverse_ops(const CigBuf<S> &b, int n) {
+template <class CB>
+AMP_HD void reverse_ops(const CB &b, int n) {
     for (int i = 0, j = n - 1; i < j; ++i, --j) {
         uint32_t t = b.get(i);
         b.set(i, b.get(j));
@@ -62,9 +63,9 @@ AMP_HD void reverse_ops(const CigBuf<S> &b, int n) {
 }
 
 // Streams ops into a buffer, folding runs of the same op (the effect of fix_cigar, A:415-423).
-template <int S>
+template <class CB>
 struct Emitter {
-    CigBuf<S> b;
+    CB b;
     int n = 0;
     uint32_t pend = 0;
     bool has = false;
@@ -86,8 +87,8 @@ struct Emitter {
 };
 
 // A:389-412 get_pos_on_query
-template <int S>
-AMP_HD int32_t pos_on_query(const CigBuf<S> &c, int n, int32_t ref_pos, int32_t ref_start, int &err) {
+template <class CB>
+AMP_HD int32_t pos_on_query(const CB &c, int n, int32_t ref_pos, int32_t ref_start, int &err) {
     int32_t query_pos = 0, cur = ref_start;
     for (int i = 0; i < n; ++i) {
         uint32_t v = c.get(i), op = v & 15u;
@@ -103,8 +104,8 @@ AMP_HD int32_t pos_on_query(const CigBuf<S> &c, int n, int32_t ref_pos, int32_t 
 }
 
 // A:363-386 get_pos_on_ref
-template <int S>
-AMP_HD int32_t pos_on_ref(const CigBuf<S> &c, int n, int32_t query_pos, int32_t ref_start, int &err) {
+template <class CB>
+AMP_HD int32_t pos_on_ref(const CB &c, int n, int32_t query_pos, int32_t ref_start, int &err) {
     int32_t cur = 0, ref_pos = ref_start;
     for (int i = 0; i < n; ++i) {
         uint32_t v = c.get(i), op = v & 15u;
@@ -120,8 +121,8 @@ AMP_HD int32_t pos_on_ref(const CigBuf<S> &c, int n, int32_t query_pos, int32_t 
 }
 
 // pysam accessors
-template <int S>
-AMP_HD int32_t reference_length(const CigBuf<S> &c, int n) {
+template <class CB>
+AMP_HD int32_t reference_length(const CB &c, int n) {
     int32_t r = 0;
     for (int i = 0; i < n; ++i) {
         uint32_t v = c.get(i), op = v & 15u;
@@ -129,8 +130,8 @@ AMP_HD int32_t reference_length(const CigBuf<S> &c, int n) {
     }
     return r ? r : 1;
 }
-template <int S>
-AMP_HD int32_t query_alignment_start(const CigBuf<S> &c, int n, int32_t lseq, int &err) {
+template <class CB>
+AMP_HD int32_t query_alignment_start(const CB &c, int n, int32_t lseq, int &err) {
     int32_t off = 0;
     for (int i = 0; i < n; ++i) {
         uint32_t v = c.get(i), op = v & 15u;
@@ -144,8 +145,8 @@ AMP_HD int32_t query_alignment_start(const CigBuf<S> &c, int n, int32_t lseq, in
     }
     return off;
 }
-template <int S>
-AMP_HD int32_t query_alignment_end(const CigBuf<S> &c, int n, int32_t lseq, int &err) {
+template <class CB>
+AMP_HD int32_t query_alignment_end(const CB &c, int n, int32_t lseq, int &err) {
     int32_t end = lseq;
     if (end == 0) {
         for (int i = 0; i < n; ++i) {
@@ -176,8 +177,8 @@ AMP_HD void py_slice(int32_t a, int32_t b, int32_t L, int32_t &lo, int32_t &hi) 
 
 // Primer clip from the front of `src` (A:467-510; the end clip A:524-555 runs it over the
 // reversed CIGAR without position tracking).  Returns the reference advance.
-template <int S, bool TRACK>
-AMP_HD int32_t primer_clip(const CigBuf<S> &src, int n, bool reversed, int32_t del, Emitter<S> &e, int &err) {
+template <bool TRACK, class CB>
+AMP_HD int32_t primer_clip(const CB &src, int n, bool reversed, int32_t del, Emitter<CB> &e, int &err) {
     bool pos_start = false;
     int32_t start_pos = 0;
     for (int i = 0; i < n; ++i) {
@@ -206,8 +207,8 @@ AMP_HD int32_t primer_clip(const CigBuf<S> &src, int n, bool reversed, int32_t d
 }
 
 // Quality clip from the front of `src` (A:597-622; A:658-683 over the reversed CIGAR).
-template <int S>
-AMP_HD void quality_clip(const CigBuf<S> &src, int n, bool reversed, int32_t del, Emitter<S> &e, int &err) {
+template <class CB>
+AMP_HD void quality_clip(const CB &src, int n, bool reversed, int32_t del, Emitter<CB> &e, int &err) {
     for (int i = 0; i < n; ++i) {
         uint32_t v = src.get(reversed ? n - 1 - i : i), op = v & 15u;
         int32_t len = (int32_t)(v >> 4);
@@ -260,9 +261,9 @@ struct TrimState {
 
 // Stage 1+2 of trim_read: primer clips (A:450-558).  `cur` holds the CIGAR, `tmp` is scratch
 // of the same capacity (n + 3); on return `cur` is the buffer holding the result.
-template <int S>
+template <class CB>
 AMP_HD void trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
-                         CigBuf<S> &cur, CigBuf<S> &tmp) {
+                         CB &cur, CB &tmp) {
     const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
     const int32_t rs = st.pos;
     if ((uint32_t)rs >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }       // A:450
@@ -276,41 +277,41 @@ AMP_HD void trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t
         st.flags |= AMP_TRIM_PRIMER_START;
         int32_t del = pos_on_query(cur, st.n, left_max_end + 1, st.pos, st.err);           // A:463
         if (st.err) return;
-        Emitter<S> e{tmp};
-        int32_t adv = primer_clip<S, true>(cur, st.n, false, del, e, st.err);
+        Emitter<CB> e{tmp};
+        int32_t adv = primer_clip<true>(cur, st.n, false, del, e, st.err);
         if (st.err) return;
         st.n = e.finish();
         st.pos += adv;                                                                     // A:514
-        CigBuf<S> t = cur; cur = tmp; tmp = t;
+        CB t = cur; cur = tmp; tmp = t;
     }
     if (!(is_paired && isize_flag && !is_reverse) && right_min_start >= 0) {               // A:517
         st.flags |= AMP_TRIM_PRIMER_END;
         int32_t del = lseq - pos_on_query(cur, st.n, right_min_start, st.pos, st.err);     // A:520
         if (st.err) return;
-        Emitter<S> e{tmp};
-        primer_clip<S, false>(cur, st.n, true, del, e, st.err);
+        Emitter<CB> e{tmp};
+        primer_clip<false>(cur, st.n, true, del, e, st.err);
         if (st.err) return;
         st.n = e.finish();
         reverse_ops(tmp, st.n);                                                            // A:558
-        CigBuf<S> t = cur; cur = tmp; tmp = t;
+        CB t = cur; cur = tmp; tmp = t;
     }
 }
 
 // Stage 3 of trim_read given the scan result `i` of quality_scan (A:589-625, A:651-686).
-template <int S>
+template <class CB>
 AMP_HD void trim_quality_apply(TrimState &st, bool is_reverse, int32_t i, int32_t qlen, int32_t qs,
-                               CigBuf<S> &cur, CigBuf<S> &tmp) {
+                               CB &cur, CB &tmp) {
     if (is_reverse) {
         const int32_t del = i;
         int32_t start_pos = pos_on_ref(cur, st.n, del + qs - 1, st.pos, st.err);           // A:591
         if (st.err) return;
         if (start_pos > st.pos) {                                                          // A:594
             st.flags |= AMP_TRIM_QUALITY;
-            Emitter<S> e{tmp};
+            Emitter<CB> e{tmp};
             quality_clip(cur, st.n, false, del, e, st.err);
             if (st.err) return;
             st.n = e.finish();                              // reference_start is NOT advanced
-            CigBuf<S> t = cur; cur = tmp; tmp = t;
+            CB t = cur; cur = tmp; tmp = t;
         }
     } else {
         const int32_t del = qlen - i;
@@ -318,20 +319,20 @@ AMP_HD void trim_quality_apply(TrimState &st, bool is_reverse, int32_t i, int32_
         if (st.err) return;
         if (del != 0) {                                                                    // A:656
             st.flags |= AMP_TRIM_QUALITY;
-            Emitter<S> e{tmp};
+            Emitter<CB> e{tmp};
             quality_clip(cur, st.n, true, del, e, st.err);
             if (st.err) return;
             st.n = e.finish();
             reverse_ops(tmp, st.n);                                                        // A:686
-            CigBuf<S> t = cur; cur = tmp; tmp = t;
+            CB t = cur; cur = tmp; tmp = t;
         }
     }
 }
 
 // Aligned-quality window [lo, lo+qlen) of A:561 for the current CIGAR; sets err like the
 // pysam accessors do.  Returns false when the read cannot be quality-trimmed.
-template <int S>
-AMP_HD bool quality_window(TrimState &st, int32_t lseq, bool have_qual, const CigBuf<S> &cur,
+template <class CB>
+AMP_HD bool quality_window(TrimState &st, int32_t lseq, bool have_qual, const CB &cur,
                            int32_t &qs, int32_t &lo, int32_t &qlen) {
     if (lseq == 0) { st.err = AMP_RS_NO_QUAL; return false; }
     qs = query_alignment_start(cur, st.n, lseq, st.err);
@@ -346,9 +347,9 @@ AMP_HD bool quality_window(TrimState &st, int32_t lseq, bool have_qual, const Ci
 }
 
 // Whole trim_read (A:426-687) for one read, scanning qualities serially.
-template <int S>
+template <class CB>
 AMP_HD void trim_read_serial(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
-                             const uint8_t *qual, bool have_qual, CigBuf<S> &cur, CigBuf<S> &tmp) {
+                             const uint8_t *qual, bool have_qual, CB &cur, CB &tmp) {
     trim_primers(P, st, flag, tlen, lseq, cur, tmp);
     if (st.err) return;
     int32_t qs, lo, qlen;
@@ -370,13 +371,13 @@ AMP_HD uint32_t base_code(const uint8_t *seq, int64_t base_off, int32_t q) {
 }
 
 // Iterator over get_aligned_pairs() without materialising the list.
-template <int S>
+template <class CB>
 struct PairIter {
-    CigBuf<S> c;
+    CB c;
     int n, k;
     int32_t j, len, q, r;
     uint32_t op;
-    AMP_HD void init(const CigBuf<S> &cig, int nops, int32_t ref_start) {
+    AMP_HD void init(const CB &cig, int nops, int32_t ref_start) {
         c = cig; n = nops; k = -1; j = 0; len = 0; q = 0; r = ref_start; op = OP_H;
     }
     // fetches the next pair; pq/pr = -1 for None
@@ -397,8 +398,8 @@ struct PairIter {
 
 // update_base_counts (A:690-753) for one read as an exact sequential walk.  Sink provides
 //   void add(int32_t ref_pos, uint32_t col)   and   void event(int32_t ref_pos, int32_t from, int32_t to)
-template <int S, class Sink>
-AMP_HD int count_read_walk(const KParams &P, const CigBuf<S> &cig, int n, int32_t ref_start, int32_t lseq,
+template <class CB, class Sink>
+AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_start, int32_t lseq,
                            const uint8_t *seq, int64_t base_off, const uint8_t *qual, bool have_qual, Sink &sink) {
     int err = 0;
     const int32_t qs = query_alignment_start(cig, n, lseq, err);                           // A:700
@@ -409,7 +410,7 @@ AMP_HD int count_read_walk(const KParams &P, const CigBuf<S> &cig, int n, int32_
     const int32_t ref_end = ref_start + reference_length(cig, n);                          // A:705
     const uint32_t G = (uint32_t)P.ref_len;
     const int32_t mq = P.min_quality;
-    PairIter<S> it;
+    PairIter<CB> it;
     it.init(cig, n, ref_start);
     int32_t q, r;
     bool pending = false;  // a pair fetched by the insertion scan and handed back (A:743)

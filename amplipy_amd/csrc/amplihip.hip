@@ -70,7 +70,8 @@ struct amp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timed = false;
     int n_cu = 256;
-    int kernel_variant = 1;       // 1 = one lane per read (reference kernels), 2 = tile kernel
+    int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = tile kernel
+    uint32_t phases = 0xFFFFFFFFu; // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
     char err[320] = {0};
 };
 
@@ -135,13 +136,17 @@ struct DevSink {
 };
 
 
-// Variant 1: one lane per read, everything serial per lane, CIGAR ping-pong in global memory.
-// Kept as the simple reference kernel the tile kernel is A/B-checked against on the GPU.
-__global__ void __launch_bounds__(256)
-k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-             amp_ins_event *ev, unsigned long long *ctr, long long ev_cap) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rd.n_reads) return;
+struct NullSink {   // dry run: only the status matters
+    __device__ void add(int32_t, uint32_t) {}
+    __device__ void event(int32_t, int32_t, int32_t) {}
+};
+
+// One read, start to finish, on one lane with the serial code of amp_read.hpp (CIGAR ping-pong
+// in global memory).  status_only: the tile kernel already counted this read and only needs
+// to know which error comes first in pair order.
+__device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
+                                    uint32_t *scratch, uint32_t *counts, amp_ins_event *ev, unsigned long long *ctr,
+                                    long long ev_cap, bool status_only) {
     const uint32_t c0 = rd.cig_off32[i];
     const int n = (int)(rd.cig_off32[i + 1] - c0);
     const size_t slot = (size_t)c0 + 3 * (size_t)i;
@@ -153,15 +158,20 @@ k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32
     const uint8_t *qual = rd.qual + boff;
     const bool have_qual = lseq > 0 && qual[0] != 0xFF;
     TrimState st{rd.pos[i], n, 0u, 0};
-    if (P.do_trim) trim_read_serial<1>(P, st, rd.flag[i], rd.tlen[i], lseq, qual, have_qual, cur, tmp);
+    if (P.do_trim) trim_read_serial(P, st, rd.flag[i], rd.tlen[i], lseq, qual, have_qual, cur, tmp);
     if (!st.err && cur.p != home) {
         for (int k = 0; k < st.n; ++k) home[k] = cur.get(k);
         cur.p = home;
     }
     int err = st.err;
     if (!err && P.do_count) {
-        DevSink sink{counts, ev, ctr, ev_cap, (uint32_t)(read_base + (uint64_t)i)};
-        err = count_read_walk<1>(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, sink);
+        if (status_only) {
+            NullSink ns;
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, ns);
+        } else {
+            DevSink sink{counts, ev, ctr, ev_cap, (uint32_t)(read_base + (uint64_t)i)};
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, sink);
+        }
     }
     if (out.new_pos) out.new_pos[i] = st.pos;
     if (out.new_ncig) out.new_ncig[i] = st.err ? 0u : (uint32_t)st.n;
@@ -169,6 +179,29 @@ k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32
     if (out.trim_flags) out.trim_flags[i] = st.err ? (uint8_t)0 : (uint8_t)st.flags;
     if (out.status) out.status[i] = (uint8_t)err;
     if (err) atomicAdd(&ctr[2], 1ull);
+}
+
+// Variant 1: every read on its own lane.  Kept as the simple kernel the tile kernel is
+// A/B-checked against on the GPU.
+__global__ void __launch_bounds__(256)
+k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
+             amp_ins_event *ev, unsigned long long *ctr, long long ev_cap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rd.n_reads) return;
+    process_read_serial(P, rd, i, read_base, out, scratch, counts, ev, ctr, ev_cap, false);
+}
+
+// Second pass of variant 2: the reads the tile kernel put on its deferred list.
+__global__ void __launch_bounds__(256)
+k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
+                 amp_ins_event *ev, unsigned long long *ctr, long long ev_cap, const uint32_t *dlist) {
+    const unsigned long long cnt = ctr[3];
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
+         k += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t e = dlist[k];
+        process_read_serial(P, rd, (int64_t)(e & 0x7FFFFFFFu), read_base, out, scratch, counts, ev, ctr, ev_cap,
+                            (e & DEFER_STATUS_ONLY) != 0);
+    }
 }
 
 __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
@@ -299,6 +332,8 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
     const char *v = getenv("AMPLIHIP_KERNEL");
     if (v && (v[0] == '1' || v[0] == '2')) c->kernel_variant = v[0] - '0';
+    v = getenv("AMPLIHIP_PHASES");
+    if (v) c->phases = (uint32_t)strtoul(v, nullptr, 0);
     *out = c;
     return AMP_OK;
 }
@@ -406,12 +441,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         }
     }
     KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end};
+    if (n > 0x7FFFFFFFll) return AMP_EINVAL;
     const size_t slots = (size_t)rd->n_cig + 3 * (size_t)n;
     DevOut out{o ? o->new_pos : nullptr, o ? o->new_ncig : nullptr, o ? o->new_cig : nullptr, o ? o->ref_len : nullptr,
                o ? o->trim_flags : nullptr, o ? o->status : nullptr};
-    HIPCHK(c, c->scratch.ensure(slots * 4 * (out.new_cig ? 1 : 2)));
+    // scratch: [CIGAR ping-pong slots][deferred list][trimmed CIGARs when the caller does not want them]
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
-    if (!out.new_cig) { out.new_cig = scr; scr += slots; }  // trimmed CIGARs not requested: keep them internal
+    uint32_t *dlist = scr + slots;
+    if (!out.new_cig) out.new_cig = dlist + n;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (c->kernel_variant == 1) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -420,11 +458,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
     } else {
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr[3], 0, sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int rc = tile_launch(P, *rd, read_base, out, scr, c->d_counts, c->events.as<amp_ins_event>(), c->d_ctr,
-                             (long long)c->ev_cap, c->n_cu, c->stream);
+        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, c->events.as<amp_ins_event>(), c->d_ctr,
+                             (long long)c->ev_cap, dlist, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+        k_reads_deferred<<<(unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 4), 256, 0, c->stream>>>(
+            P, *rd, read_base, out, scr, c->d_counts, c->events.as<amp_ins_event>(), c->d_ctr, (long long)c->ev_cap, dlist);
+        HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
     c->timed = true;

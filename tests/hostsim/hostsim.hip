@@ -37,7 +37,7 @@ extern "C" int sim_process_range(int32_t min_quality, int32_t window, int32_t do
         const uint8_t *qual = rd->qual + boff;
         bool have_qual = lseq > 0 && qual[0] != 0xFF;
         TrimState st{rd->pos[i], n, 0u, 0};
-        if (do_trim) trim_read_serial<1>(P, st, rd->flag[i], rd->tlen[i], lseq, qual, have_qual, cur, tmp);
+        if (do_trim) trim_read_serial(P, st, rd->flag[i], rd->tlen[i], lseq, qual, have_qual, cur, tmp);
         if (out) {
             if (out->new_pos) out->new_pos[i] = st.pos;
             if (out->new_ncig) out->new_ncig[i] = st.err ? 0 : st.n;
@@ -48,7 +48,7 @@ extern "C" int sim_process_range(int32_t min_quality, int32_t window, int32_t do
         int err = st.err;
         if (!err && do_count) {
             HostSink sink{counts, &ev, (uint32_t)(read_base + (uint64_t)i)};
-            err = count_read_walk<1>(P, cur, st.n, st.pos, lseq, rd->seq, boff, qual, have_qual, sink);
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd->seq, boff, qual, have_qual, sink);
         }
         if (out && out->status) out->status[i] = (uint8_t)err;
     }
