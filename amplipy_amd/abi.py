@@ -49,7 +49,13 @@ class AmpDevReads(C.Structure):
 class AmpCallParams(C.Structure):
     _fields_ = [("min_depth_consensus", C.c_int32), ("min_depth_variants", C.c_int32),
                 ("min_freq_consensus", C.c_double), ("min_freq_variants", C.c_double),
-                ("run_consensus", C.c_int32), ("run_variants", C.c_int32)]
+                ("run_consensus", C.c_int32), ("run_variants", C.c_int32),
+                ("full_ranking", C.c_int32), ("reserved", C.c_int32)]
+
+
+POS_CALL_DTYPE = np.dtype([("total_depth", "<u4"), ("ref_count", "<u4"), ("order", "<u4"), ("consensus_sym", "i1"),
+                           ("flags", "u1"), ("alt_mask", "u1"), ("pad", "u1")])
+CALL_VARIANT, CALL_GT_HAS_REF, CALL_INS_RELEVANT = 1, 2, 4
 
 
 def ptr(a):

@@ -43,6 +43,20 @@ struct DevOut {
     uint8_t *status;
 };
 
+// Where insertion events go: the event list (bounded by cap; the cursor keeps counting so the
+// host can detect a short reservation) and the per-position event tally used by calling.
+struct EventBuf {
+    amp_ins_event *ev;
+    unsigned long long *ctr;   // [0] events, [1] bound, [2] error reads, [3] deferred reads
+    uint32_t *ins_at;          // [ref_len]
+    long long cap;
+    __device__ void record(int32_t pos, uint32_t read, int32_t lo, int32_t hi) const {
+        unsigned long long idx = atomicAdd(&ctr[0], 1ull);
+        if ((long long)idx < cap) ev[idx] = amp_ins_event{pos, read, lo, hi};
+        atomicAdd(&ins_at[pos], 1u);
+    }
+};
+
 // A CIGAR held as BAM words.  Every function below is generic over the buffer class CB, which
 // provides get(i) / set(i, v) and a pointer member p: CigBuf<1> is contiguous global memory;
 // the tile kernel uses an LDS-address-space buffer with one column per lane.

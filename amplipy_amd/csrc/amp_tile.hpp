@@ -80,9 +80,7 @@ struct TileCtx {
     int32_t win_base;
     uint32_t wlim;      // min(T_W, ref_len - win_base): window positions that are real
     uint32_t *counts;
-    amp_ins_event *ev;
-    unsigned long long *ctr;
-    long long ev_cap;
+    EventBuf eb;
     uint32_t G;
 };
 
@@ -96,10 +94,7 @@ struct TileSink {
     const TileCtx &t;
     uint32_t read;
     __device__ void add(int32_t r, uint32_t col) { tile_add(t, r, col); }
-    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
-        unsigned long long idx = atomicAdd(&t.ctr[0], 1ull);
-        if ((long long)idx < t.ev_cap) t.ev[idx] = amp_ins_event{pos, read, lo, hi};
-    }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) { t.eb.record(pos, read, lo, hi); }
 };
 
 // The skip-ahead variant of the exact walk for REGULAR reads: M/=/X runs and the end clips
@@ -267,8 +262,9 @@ __device__ __forceinline__ int find_read(const lds_u32 *cb, uint32_t c, float in
 
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(T_WAVES * 64)
-k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, amp_ins_event *ev,
-       unsigned long long *ctr, long long ev_cap, uint32_t *dlist, int tiles_per_block, uint32_t phases) {
+k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
+       int tiles_per_block, uint32_t phases) {
+    unsigned long long *const ctr = eb.ctr;
     __shared__ BlockLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t n = rd.n_reads;
@@ -283,7 +279,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const st = (lds_u32 *)L.wv[wave].st;
     lds_u32 *const cigA = (lds_u32 *)L.wv[wave].cigA;
     lds_u32 *const cigB = (lds_u32 *)L.wv[wave].cigB;
-    TileCtx tc{win, 0, 0u, counts, ev, ctr, ev_cap, (uint32_t)P.ref_len};
+    TileCtx tc{win, 0, 0u, counts, eb, (uint32_t)P.ref_len};
     const int32_t mq = P.min_quality;
     unsigned long long n_err = 0;
 
@@ -601,15 +597,15 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 }
 
 static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
-                              uint32_t *counts, amp_ins_event *ev, unsigned long long *ctr, long long ev_cap,
-                              uint32_t *dlist, int n_cu, uint32_t phases, hipStream_t stream) {
+                              uint32_t *counts, const EventBuf &eb, uint32_t *dlist, int n_cu, uint32_t phases,
+                              hipStream_t stream) {
     const int64_t n_tiles = (rd.n_reads + TILE - 1) / TILE;
     if (n_tiles == 0) return 0;
     int64_t max_blocks = (int64_t)n_cu * 2;
     int64_t tpb = (n_tiles + max_blocks - 1) / max_blocks;
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
     int64_t grid = (n_tiles + tpb - 1) / tpb;
-    k_tile<<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, ev, ctr, ev_cap, dlist, (int)tpb, phases);
+    k_tile<<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
     return (int)hipGetLastError();
 }
 

@@ -61,7 +61,10 @@ struct amp_ctx {
     DBuf events;                  // amp_ins_event[ev_cap]
     int64_t ev_cap = 0;
     bool ev_reserved = false;     // caller sized the buffer: skip the bound pre-pass
-    unsigned long long *d_ctr = nullptr;  // [0] events recorded, [1] event bound, [2] error-read count
+    unsigned long long *d_ctr = nullptr;  // [0] events recorded, [1] event bound, [2] error reads, [3] deferred reads
+    uint32_t *d_ins_at = nullptr;         // [ref_len] insertion events per reference position
+    uint8_t *d_ref = nullptr;             // [ref_len] reference sequence, ASCII (amp_set_reference)
+    bool have_ref = false;
     // staging for the host-pointer path
     DBuf s_pos, s_flag, s_tlen, s_lseq, s_cigoff, s_cig, s_seqoff, s_seq, s_qual;
     DBuf o_pos, o_ncig, o_cig, o_reflen, o_flags, o_status;
@@ -124,15 +127,10 @@ __global__ void k_event_bound(int64_t n, const uint32_t *__restrict__ cig_off, c
 
 struct DevSink {
     uint32_t *counts;
-    amp_ins_event *ev;
-    unsigned long long *ctr;
-    long long ev_cap;
+    const EventBuf &eb;
     uint32_t read;
     __device__ void add(int32_t r, uint32_t col) { atomicAdd(&counts[(size_t)r * AMP_NSYM + col], 1u); }
-    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
-        unsigned long long idx = atomicAdd(&ctr[0], 1ull);
-        if ((long long)idx < ev_cap) ev[idx] = amp_ins_event{pos, read, lo, hi};
-    }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) { eb.record(pos, read, lo, hi); }
 };
 
 
@@ -145,8 +143,7 @@ struct NullSink {   // dry run: only the status matters
 // in global memory).  status_only: the tile kernel already counted this read and only needs
 // to know which error comes first in pair order.
 __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
-                                    uint32_t *scratch, uint32_t *counts, amp_ins_event *ev, unsigned long long *ctr,
-                                    long long ev_cap, bool status_only) {
+                                    uint32_t *scratch, uint32_t *counts, const EventBuf &eb, bool status_only) {
     const uint32_t c0 = rd.cig_off32[i];
     const int n = (int)(rd.cig_off32[i + 1] - c0);
     const size_t slot = (size_t)c0 + 3 * (size_t)i;
@@ -169,7 +166,7 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
             NullSink ns;
             err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, ns);
         } else {
-            DevSink sink{counts, ev, ctr, ev_cap, (uint32_t)(read_base + (uint64_t)i)};
+            DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
             err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, sink);
         }
     }
@@ -178,29 +175,27 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
     if (out.ref_len) out.ref_len[i] = st.err ? 0 : reference_length(cur, st.n);
     if (out.trim_flags) out.trim_flags[i] = st.err ? (uint8_t)0 : (uint8_t)st.flags;
     if (out.status) out.status[i] = (uint8_t)err;
-    if (err) atomicAdd(&ctr[2], 1ull);
+    if (err) atomicAdd(&eb.ctr[2], 1ull);
 }
 
 // Variant 1: every read on its own lane.  Kept as the simple kernel the tile kernel is
 // A/B-checked against on the GPU.
 __global__ void __launch_bounds__(256)
-k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-             amp_ins_event *ev, unsigned long long *ctr, long long ev_cap) {
+k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts, EventBuf eb) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rd.n_reads) return;
-    process_read_serial(P, rd, i, read_base, out, scratch, counts, ev, ctr, ev_cap, false);
+    process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, false);
 }
 
 // Second pass of variant 2: the reads the tile kernel put on its deferred list.
 __global__ void __launch_bounds__(256)
 k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 amp_ins_event *ev, unsigned long long *ctr, long long ev_cap, const uint32_t *dlist) {
-    const unsigned long long cnt = ctr[3];
+                 EventBuf eb, const uint32_t *dlist) {
+    const unsigned long long cnt = eb.ctr[3];
     for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
          k += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t e = dlist[k];
-        process_read_serial(P, rd, (int64_t)(e & 0x7FFFFFFFu), read_base, out, scratch, counts, ev, ctr, ev_cap,
-                            (e & DEFER_STATUS_ONLY) != 0);
+        process_read_serial(P, rd, (int64_t)(e & 0x7FFFFFFFu), read_base, out, scratch, counts, eb, (e & DEFER_STATUS_ONLY) != 0);
     }
 }
 
@@ -209,29 +204,73 @@ __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
     if (i < n) dst[i] += src[i];
 }
 
-// Calling, integer part (A:756-771): per position the total of the six base symbols and
-// their order under sorted(..., reverse=True): count descending, ties by symbol descending
-// ('T' > 'N' > 'G' > 'C' > 'A' > '-').  order = six 3-bit column indices, best first.
-__global__ void k_rank_bases(const uint32_t *__restrict__ counts, int32_t ref_len, uint32_t *__restrict__ total6,
-                             uint32_t *__restrict__ order) {
+// Calling (A:756-771 alleles_from_counts + A:917-952), one lane per reference position.
+// Everything that does not depend on the TEXT of an insertion allele is decided here: total
+// depth, the six base symbols ranked like sorted(..., reverse=True) (count descending, ties by
+// symbol descending: 'T' > 'N' > 'G' > 'C' > 'A' > '-'), consensus symbol, variant record.
+// An insertion string can only matter when the position's insertion events could out-rank
+// the best base symbol or reach the variant frequency threshold; such positions are flagged
+// AMP_CALL_INS_RELEVANT and finished by the host from the event list.
+__global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ins_at,
+                       const uint8_t *__restrict__ ref, int32_t ref_len, amp_call_params pr, amp_pos_call *__restrict__ out,
+                       unsigned long long *n_relevant) {
     int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= ref_len) return;
-    // columns in descending symbol order: T(3) N(4) G(2) C(1) A(0) -(5)
-    const int desc[6] = {3, 4, 2, 1, 0, 5};
+    const int desc[6] = {3, 4, 2, 1, 0, 5};            // T N G C A -
+    const char sym_of[6] = {'A', 'C', 'G', 'T', 'N', '-'};
     uint32_t c[6], idx[6];
-    uint32_t tot = 0;
-    for (int k = 0; k < 6; ++k) { idx[k] = desc[k]; c[k] = counts[(size_t)p * AMP_NSYM + desc[k]]; tot += c[k]; }
-    // stable insertion sort by count descending keeps the symbol order for ties
-    for (int a = 1; a < 6; ++a) {
+    uint64_t total = ins_at[p];
+    for (int k = 0; k < 6; ++k) { idx[k] = desc[k]; c[k] = counts[(size_t)p * AMP_NSYM + desc[k]]; total += c[k]; }
+    for (int a = 1; a < 6; ++a) {                      // stable: ties keep the symbol order
         uint32_t cv = c[a], iv = idx[a];
         int b = a - 1;
         while (b >= 0 && c[b] < cv) { c[b + 1] = c[b]; idx[b + 1] = idx[b]; --b; }
         c[b + 1] = cv; idx[b + 1] = iv;
     }
-    uint32_t o = 0;
-    for (int k = 0; k < 6; ++k) o |= idx[k] << (3 * k);
-    total6[p] = tot;
-    order[p] = o;
+    uint32_t order = 0, nnz = 0;
+    for (int k = 0; k < 6; ++k) { order |= idx[k] << (3 * k); nnz += c[k] != 0; }
+    amp_pos_call o;
+    o.total_depth = (uint32_t)total;
+    o.order = order | (nnz << 18);
+    o.consensus_sym = -1;
+    o.flags = 0; o.alt_mask = 0; o.ref_count = 0;
+    const uint32_t ins = ins_at[p];
+    const double dtot = (double)total;
+    bool relevant = false;
+    if (ins) {
+        relevant = pr.full_ranking != 0 || ins >= c[0];
+        if (pr.run_variants && (double)ins / dtot >= pr.min_freq_variants) relevant = true;
+    }
+    if (pr.run_consensus && nnz && (int64_t)c[0] >= (int64_t)pr.min_depth_consensus &&
+        (double)c[0] / dtot >= pr.min_freq_consensus) o.consensus_sym = (int8_t)idx[0];       // A:928-929
+    if (pr.run_variants) {                                                                     // A:933-951
+        const char rs = (char)ref[p];
+        uint32_t rc = 0; double rf = 0.0; uint32_t n_alt = 0, altm = 0;
+        for (int k = 0; k < 6; ++k) {
+            if (!c[k]) continue;
+            double f = (double)c[k] / dtot;
+            if (sym_of[idx[k]] == rs) { rc = c[k]; rf = f; }
+            else if (f >= pr.min_freq_variants) { altm |= 1u << k; ++n_alt; }
+        }
+        o.ref_count = rc; o.alt_mask = (uint8_t)altm;
+        if ((int64_t)total >= (int64_t)pr.min_depth_variants && n_alt) o.flags |= AMP_CALL_VARIANT;
+        if ((int64_t)rc >= (int64_t)pr.min_depth_variants && rf >= pr.min_freq_variants) o.flags |= AMP_CALL_GT_HAS_REF;
+    }
+    if (relevant) { o.flags |= AMP_CALL_INS_RELEVANT; atomicAdd(n_relevant, 1ull); }
+    out[p] = o;
+}
+
+// Copies the text of insertion events (SEQ[q_from:q_to], A:736-738, upper-cased like A:702)
+// out of a device-resident batch: one lane per event.
+__global__ void k_event_strings(amp_dev_reads rd, uint64_t read_base, int64_t n_ev, const amp_ins_event *__restrict__ ev,
+                                const uint64_t *__restrict__ off, uint8_t *__restrict__ text) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ev) return;
+    const char nt16[17] = "=ACMGRSVTWYHKDBN";
+    const int64_t i = (int64_t)((uint64_t)ev[e].read - read_base);
+    const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
+    uint8_t *dst = text + off[e];
+    for (int32_t q = ev[e].q_from; q < ev[e].q_to; ++q) *dst++ = (uint8_t)nt16[base_code(rd.seq, boff, q)];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -319,12 +358,14 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     auto fail = [&](int rc) { amp_ctx_destroy(c); return rc; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(AMP_EHIP);
     c->own_stream = true;
-    size_t cb = (size_t)ref_len * AMP_NSYM * sizeof(uint32_t);
+    size_t cb = (size_t)ref_len * AMP_DEV_COLS * sizeof(uint32_t);   // counts [G][6] followed by the insertion tally [G]
     if (hipMalloc((void **)&c->d_counts, cb) != hipSuccess) return fail(AMP_ENOMEM);
     c->own_counts = true;
+    c->d_ins_at = c->d_counts + (size_t)ref_len * AMP_NSYM;
     if (hipMalloc((void **)&c->d_min_start, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_max_end, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_ctr, 8 * sizeof(unsigned long long)) != hipSuccess) return fail(AMP_ENOMEM);
+    if (hipMalloc((void **)&c->d_ref, (size_t)ref_len) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMemsetAsync(c->d_counts, 0, cb, c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -346,6 +387,7 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->d_min_start) (void)hipFree(c->d_min_start);
     if (c->d_max_end) (void)hipFree(c->d_max_end);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_ref) (void)hipFree(c->d_ref);
     DBuf *bufs[] = {&c->events, &c->s_pos, &c->s_flag, &c->s_tlen, &c->s_lseq, &c->s_cigoff, &c->s_cig, &c->s_seqoff,
                     &c->s_seq, &c->s_qual, &c->o_pos, &c->o_ncig, &c->o_cig, &c->o_reflen, &c->o_flags, &c->o_status,
                     &c->scratch, &c->call_buf};
@@ -371,11 +413,12 @@ int amp_ctx_set_stream(amp_ctx *c, void *s) {
 int amp_ctx_bind_counts(amp_ctx *c, void *dev_counts) {
     if (!c || !dev_counts) return AMP_EINVAL;
     Guard g(c);
-    size_t cb = (size_t)c->ref_len * AMP_NSYM * sizeof(uint32_t);
+    size_t cb = (size_t)c->ref_len * AMP_DEV_COLS * sizeof(uint32_t);
     HIPCHK(c, hipMemcpyAsync(dev_counts, c->d_counts, cb, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->own_counts) (void)hipFree(c->d_counts);
     c->d_counts = (uint32_t *)dev_counts;
+    c->d_ins_at = c->d_counts + (size_t)c->ref_len * AMP_NSYM;
     c->own_counts = false;
     return AMP_OK;
 }
@@ -450,22 +493,21 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;
     if (!out.new_cig) out.new_cig = dlist + n;
+    const EventBuf eb{c->events.as<amp_ins_event>(), c->d_ctr, c->d_ins_at, (long long)c->ev_cap};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (c->kernel_variant == 1) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        k_reads_lane<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts,
-                                                                        c->events.as<amp_ins_event>(), c->d_ctr, (long long)c->ev_cap);
+        k_reads_lane<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
     } else {
         HIPCHK(c, hipMemsetAsync(&c->d_ctr[3], 0, sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, c->events.as<amp_ins_event>(), c->d_ctr,
-                             (long long)c->ev_cap, dlist, c->n_cu, c->phases, c->stream);
+        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         k_reads_deferred<<<(unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 4), 256, 0, c->stream>>>(
-            P, *rd, read_base, out, scr, c->d_counts, c->events.as<amp_ins_event>(), c->d_ctr, (long long)c->ev_cap, dlist);
+            P, *rd, read_base, out, scr, c->d_counts, eb, dlist);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
@@ -596,7 +638,7 @@ int amp_error_reads(amp_ctx *c, int64_t *n) {  // reads with a non-zero status s
 int amp_reset(amp_ctx *c) {
     if (!c) return AMP_EINVAL;
     Guard g(c);
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_NSYM * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_DEV_COLS * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
     return AMP_OK;
 }
@@ -618,7 +660,7 @@ int amp_reduce(amp_ctx *c, void *comm, int root) {
         if (lib) { f_red = dlsym(lib, "ncclReduce"); f_all = dlsym(lib, "ncclAllReduce"); }
     }
     if (!f_red || !f_all) { snprintf(c->err, sizeof(c->err), "RCCL symbols not found"); return AMP_ERCCL; }
-    const size_t cnt = (size_t)c->ref_len * AMP_NSYM;
+    const size_t cnt = (size_t)c->ref_len * AMP_DEV_COLS;
     const int nccl_uint32 = 3, nccl_sum = 0;
     int rc = root < 0 ? ((nccl_allreduce_fn)f_all)(c->d_counts, c->d_counts, cnt, nccl_uint32, nccl_sum, comm, c->stream)
                       : ((nccl_reduce_fn)f_red)(c->d_counts, c->d_counts, cnt, nccl_uint32, nccl_sum, root, comm, c->stream);
@@ -630,113 +672,56 @@ int amp_reduce(amp_ctx *c, void *comm, int root) {
 // ---------------------------------------------------------------------------------------
 // calling (A:756-771, A:917-952)
 // ---------------------------------------------------------------------------------------
-static const char SYMS[6] = {'A', 'C', 'G', 'T', 'N', '-'};
-// Number of base symbols that sort AFTER an insertion string s in descending order is decided
-// by s's first character: compare s with each one-character symbol as Python strings.
-static inline bool str_gt_sym(const uint8_t *s, int32_t len, char sym) {  // s > sym ?
-    if (len == 0) return false;                 // '' < anything
-    if ((char)s[0] != sym) return (unsigned char)s[0] > (unsigned char)sym;
-    return len > 1;                             // "Ax" > "A"
+int amp_set_reference(amp_ctx *c, const uint8_t *ref_ascii) {
+    if (!c || !ref_ascii) return AMP_EINVAL;
+    Guard g(c);
+    HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_ascii, (size_t)c->ref_len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_ref = true;
+    return AMP_OK;
 }
 
-int amp_call(amp_ctx *c, const amp_call_params *pr, const uint8_t *ref_seq, int64_t n_ins, const int32_t *ins_pos,
-             const uint32_t *ins_count, const uint8_t *const *ins_str, const int32_t *ins_len, const amp_call_out *out) {
-    if (!c || !pr || !out || n_ins < 0 || (n_ins && (!ins_pos || !ins_count || !ins_str || !ins_len))) return AMP_EINVAL;
-    if (pr->run_variants && !ref_seq) return AMP_EINVAL;
+int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out, int64_t *n_relevant) {
+    if (!c || !pr || !out) return AMP_EINVAL;
+    if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
     Guard g(c);
     const int32_t G = c->ref_len;
-    HIPCHK(c, c->call_buf.ensure((size_t)G * 8));
-    uint32_t *d_tot = c->call_buf.as<uint32_t>(), *d_ord = d_tot + G;
-    k_rank_bases<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, G, d_tot, d_ord);
+    HIPCHK(c, c->call_buf.ensure((size_t)G * sizeof(amp_pos_call)));
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, sizeof(unsigned long long), c->stream));
+    k_call<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr,
+                                                              c->call_buf.as<amp_pos_call>(), &c->d_ctr[4]);
     HIPCHK(c, hipGetLastError());
-    std::vector<uint32_t> tot((size_t)G), ord((size_t)G), cnt((size_t)G * AMP_NSYM);
-    HIPCHK(c, hipMemcpyAsync(tot.data(), d_tot, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ord.data(), d_ord, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_counts, (size_t)G * AMP_NSYM * 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long nr = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->call_buf.p, (size_t)G * sizeof(amp_pos_call), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&nr, &c->d_ctr[4], sizeof(nr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t k = 0, na = 0;
-    for (int32_t p = 0; p < G; ++p) {
-        const int64_t k0 = k;
-        uint64_t total = tot[(size_t)p];
-        while (k < n_ins && ins_pos[k] == p) { total += ins_count[k]; ++k; }
-        if (k < n_ins && ins_pos[k] < p) return AMP_EINVAL;  // rows must be sorted by position
-        const int nins = (int)(k - k0);
-        // merge: base symbols (ranked on the device) with this position's insertion rows
-        amp_allele al[6];
-        int nb = 0;
-        for (int r = 0; r < 6; ++r) {
-            int col = (ord[(size_t)p] >> (3 * r)) & 7;
-            uint32_t cv = cnt[(size_t)p * AMP_NSYM + col];
-            if (cv) al[nb++] = amp_allele{cv, col};
-        }
-        const int64_t a0 = na;
-        if (out->allele_off) out->allele_off[p] = (uint64_t)a0;
-        int n_all = nb;
-        std::vector<amp_allele> merged;
-        const amp_allele *ranked = al;
-        if (nins) {
-            merged.reserve((size_t)nb + nins);
-            std::vector<int> rows;
-            for (int j = 0; j < nins; ++j) if (ins_count[k0 + j]) rows.push_back(j);
-            // rows arrive in descending string order; stable sort by count keeps it for ties
-            std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return ins_count[k0 + a] > ins_count[k0 + b]; });
-            size_t ib = 0, ii = 0;
-            while (ib < (size_t)nb || ii < rows.size()) {
-                bool take_ins;
-                if (ib >= (size_t)nb) take_ins = true;
-                else if (ii >= rows.size()) take_ins = false;
-                else {
-                    uint32_t cb = al[ib].count, ci = ins_count[k0 + rows[ii]];
-                    if (ci != cb) take_ins = ci > cb;
-                    else take_ins = str_gt_sym(ins_str[k0 + rows[ii]], ins_len[k0 + rows[ii]], SYMS[al[ib].sym]);
-                }
-                if (take_ins) { merged.push_back(amp_allele{ins_count[k0 + rows[ii]], 6 + rows[ii]}); ++ii; }
-                else merged.push_back(al[ib++]);
-            }
-            ranked = merged.data();
-            n_all = (int)merged.size();
-        }
-        if (out->total_depth) out->total_depth[p] = (uint32_t)total;
-        if (out->n_alleles) out->n_alleles[p] = n_all;
-        if (out->alleles) {
-            if (na + n_all > out->alleles_cap) return AMP_EOVERFLOW;
-            for (int r = 0; r < n_all; ++r) out->alleles[na + r] = ranked[r];
-        }
-        na += n_all;
-        // consensus (A:928-929)
-        if (out->consensus_sym) {
-            int32_t cs = -1;
-            if (pr->run_consensus && n_all && ranked[0].count >= (uint32_t)std::max(pr->min_depth_consensus, 0) &&
-                (double)ranked[0].count / (double)total >= pr->min_freq_consensus) cs = ranked[0].sym;
-            out->consensus_sym[p] = cs;
-        }
-        // variants (A:933-951)
-        if (pr->run_variants) {
-            const char ref_symbol = (char)ref_seq[p];
-            uint64_t tot_count = 0;
-            uint32_t rc = 0; double rf = 0; int n_alt = 0;
-            for (int r = 0; r < n_all; ++r) {
-                tot_count += ranked[r].count;
-                double f = (double)ranked[r].count / (double)total;
-                bool is_ref = ranked[r].sym < 6 ? SYMS[ranked[r].sym] == ref_symbol
-                                                : (ins_len[k0 + ranked[r].sym - 6] == 1 && (char)ins_str[k0 + ranked[r].sym - 6][0] == ref_symbol);
-                uint8_t af = 0;
-                if (is_ref) { rc = ranked[r].count; rf = f; af = 2; }
-                else if (f >= pr->min_freq_variants) { af = 1; ++n_alt; }
-                if (out->allele_flags && out->alleles) out->allele_flags[a0 + r] = af;
-            }
-            uint8_t vf = 0;
-            if ((int64_t)tot_count >= (int64_t)pr->min_depth_variants && n_alt) {
-                vf |= 1;
-                if ((int64_t)rc >= (int64_t)pr->min_depth_variants && rf >= pr->min_freq_variants) vf |= 2;
-            }
-            if (out->variant_flags) out->variant_flags[p] = vf;
-            if (out->ref_count) out->ref_count[p] = rc;
-        } else {
-            if (out->variant_flags) out->variant_flags[p] = 0;
-        }
+    if (n_relevant) *n_relevant = (int64_t)nr;
+    return AMP_OK;
+}
+
+int amp_event_strings(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base, int64_t n_ev, const amp_ins_event *ev,
+                      const uint64_t *off, uint8_t *text) {
+    if (!c || !rd || n_ev < 0 || (n_ev && (!ev || !off || !text))) return AMP_EINVAL;
+    if (n_ev == 0) return AMP_OK;
+    for (int64_t e = 0; e < n_ev; ++e) {
+        uint64_t i = (uint64_t)ev[e].read - read_base;
+        if (i >= (uint64_t)rd->n_reads || ev[e].q_from < 0 || ev[e].q_to < ev[e].q_from ||
+            off[e + 1] - off[e] != (uint64_t)(ev[e].q_to - ev[e].q_from)) return AMP_EINVAL;
     }
-    if (out->allele_off) out->allele_off[G] = (uint64_t)na;
+    Guard g(c);
+    const size_t tb = (size_t)off[n_ev];
+    const size_t need = (size_t)n_ev * sizeof(amp_ins_event) + ((size_t)n_ev + 1) * 8 + tb + 64;
+    HIPCHK(c, c->call_buf.ensure(need));
+    uint8_t *base = c->call_buf.as<uint8_t>();
+    uint64_t *d_off = (uint64_t *)base;
+    amp_ins_event *d_ev = (amp_ins_event *)(base + ((size_t)n_ev + 1) * 8);
+    uint8_t *d_text = (uint8_t *)(d_ev + n_ev);
+    HIPCHK(c, hipMemcpyAsync(d_off, off, ((size_t)n_ev + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_ev, ev, (size_t)n_ev * sizeof(amp_ins_event), hipMemcpyHostToDevice, c->stream));
+    k_event_strings<<<(unsigned)((n_ev + 255) / 256), 256, 0, c->stream>>>(*rd, read_base, n_ev, d_ev, d_off, d_text);
+    HIPCHK(c, hipGetLastError());
+    if (tb) HIPCHK(c, hipMemcpyAsync(text, d_text, tb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMP_OK;
 }
 

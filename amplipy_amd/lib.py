@@ -23,7 +23,8 @@ EXPORTS = [
     "amp_ctx_bind_counts", "amp_set_primers", "amp_set_params", "amp_process_batch",
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
-    "amp_reserve_events", "amp_set_kernel_variant", "amp_call",
+    "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
+    "amp_event_strings",
 ]
 
 
@@ -182,37 +183,29 @@ class Engine:
         self._chk(self.L.amp_reset(self.h), "amp_reset")
 
     # ---- calling ---------------------------------------------------------------------
-    def call(self, params, ref_seq, ins_rows):
-        """amp_call.  ``ins_rows`` = [(ref_pos, string, count)] sorted by ref_pos then by string
-        DESCENDING.  Returns a dict of numpy arrays (see amp_call_out)."""
-        G = self.ref_len
-        n = len(ins_rows)
-        ipos = np.array([r[0] for r in ins_rows], np.int32)
-        icnt = np.array([r[2] for r in ins_rows], np.uint32)
-        strs = [r[1].encode("ascii") for r in ins_rows]
-        ilen = np.array([len(s) for s in strs], np.int32)
-        sarr = (C.c_char_p * max(n, 1))(*strs) if n else (C.c_char_p * 1)()
-        cap = G * abi.NSYM + n
-        out = {
-            "total_depth": np.zeros(G, np.uint32), "consensus_sym": np.zeros(G, np.int32),
-            "n_alleles": np.zeros(G, np.int32), "allele_off": np.zeros(G + 1, np.uint64),
-            "alleles": np.zeros(cap, np.dtype([("count", "<u4"), ("sym", "<i4")])),
-            "variant_flags": np.zeros(G, np.uint8), "ref_count": np.zeros(G, np.uint32),
-            "allele_flags": np.zeros(cap, np.uint8),
-        }
-
-        class CallOut(C.Structure):
-            _fields_ = [("total_depth", C.c_void_p), ("consensus_sym", C.c_void_p), ("n_alleles", C.c_void_p),
-                        ("allele_off", C.c_void_p), ("alleles", C.c_void_p), ("alleles_cap", C.c_int64),
-                        ("variant_flags", C.c_void_p), ("ref_count", C.c_void_p), ("allele_flags", C.c_void_p)]
-
-        co = CallOut(abi.ptr(out["total_depth"]), abi.ptr(out["consensus_sym"]), abi.ptr(out["n_alleles"]),
-                     abi.ptr(out["allele_off"]), abi.ptr(out["alleles"]), cap, abi.ptr(out["variant_flags"]),
-                     abi.ptr(out["ref_count"]), abi.ptr(out["allele_flags"]))
+    def set_reference(self, ref_seq):
         ref = np.frombuffer(ref_seq.encode("ascii") if isinstance(ref_seq, str) else bytes(ref_seq), np.uint8)
-        assert ref.size == G
-        self._chk(self.L.amp_call(self.h, C.byref(params), C.c_void_p(abi.ptr(ref)), C.c_int64(n),
-                                  C.c_void_p(abi.ptr(ipos)) if n else None, C.c_void_p(abi.ptr(icnt)) if n else None,
-                                  sarr if n else None, C.c_void_p(abi.ptr(ilen)) if n else None, C.byref(co)),
-                  "amp_call")
-        return out
+        assert ref.size == self.ref_len
+        self._chk(self.L.amp_set_reference(self.h, C.c_void_p(abi.ptr(ref))), "amp_set_reference")
+
+    def call_positions(self, params):
+        """amp_call_positions -> (structured array POS_CALL_DTYPE[ref_len], n_relevant)."""
+        out = np.zeros(self.ref_len, abi.POS_CALL_DTYPE)
+        nr = C.c_int64(0)
+        self._chk(self.L.amp_call_positions(self.h, C.byref(params), C.c_void_p(abi.ptr(out)), C.byref(nr)),
+                  "amp_call_positions")
+        return out, int(nr.value)
+
+    def event_strings_device(self, dev_reads, events, read_base=0):
+        """Strings of ``events`` (INS_EVENT_DTYPE) taken from a device-resident batch."""
+        n = events.size
+        lens = (events["q_to"] - events["q_from"]).astype(np.uint64)
+        off = np.zeros(n + 1, np.uint64)
+        np.cumsum(lens, out=off[1:])
+        text = np.zeros(max(int(off[n]), 1), np.uint8)
+        ev = np.ascontiguousarray(events)
+        self._chk(self.L.amp_event_strings(self.h, C.byref(dev_reads), C.c_uint64(read_base), C.c_int64(n),
+                                           C.c_void_p(abi.ptr(ev)), C.c_void_p(abi.ptr(off)), C.c_void_p(abi.ptr(text))),
+                  "amp_event_strings")
+        raw = text.tobytes()
+        return [raw[int(off[k]):int(off[k + 1])].decode("ascii") for k in range(n)]

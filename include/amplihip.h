@@ -34,6 +34,7 @@ extern "C" {
 #define AMP_ABI_VERSION 1
 #define AMP_NSYM 6 /* count-table columns, in this order: A C G T N '-'  (AmpliPy.py:892) */
 #define AMP_SEQ_ALIGN 8 /* every read starts on a multiple of 8 bases in seq/qual */
+#define AMP_DEV_COLS 7 /* device table: uint32[ref_len][6] counts, then uint32[ref_len] insertion-event tally */
 
 typedef enum amp_rc {
     AMP_OK = 0,
@@ -155,8 +156,8 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len);
 void amp_ctx_destroy(amp_ctx *ctx);
 /* Optional: run all work of this ctx on the caller's HIP stream (hipStream_t). */
 int amp_ctx_set_stream(amp_ctx *ctx, void *hip_stream);
-/* Optional: use caller-owned DEVICE memory (uint32[ref_len*AMP_NSYM], e.g. a torch tensor)
- * as the count table so torch.distributed can reduce it in place. Contents are kept. */
+/* Optional: use caller-owned DEVICE memory (uint32[ref_len*AMP_DEV_COLS], e.g. a torch
+ * tensor) as the device table so torch.distributed can reduce it in place. Contents are kept. */
 int amp_ctx_bind_counts(amp_ctx *ctx, void *dev_counts);
 
 /* Tables consumed by trim_read (AmpliPy.py:450-452); host pointers, length ref_len. */
@@ -188,7 +189,7 @@ int amp_add_counts(amp_ctx *ctx, const uint32_t *counts /* host, added element-w
 /* *n = number of events recorded so far; copies min(*n, cap) of them when buf != NULL. */
 int amp_get_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
 void *amp_counts_device_ptr(amp_ctx *ctx);
-/* Sum count tables over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
+/* Sum the device tables (counts + insertion tally) over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
  * (root < 0: all ranks).  comm == NULL is a no-op (single GPU). */
 int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);
 int amp_reset(amp_ctx *ctx); /* zero the count table and drop recorded events */
@@ -202,11 +203,16 @@ int amp_reserve_events(amp_ctx *ctx, int64_t cap);
  * Also settable with the environment variable AMPLIHIP_KERNEL. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
 
-/* ---- calling: alleles_from_counts + AmpliPy.py:917-952, integer/double part ---------------
- * Insertion alleles are strings, aggregated by the host into (ref_pos, count) rows sorted by
- * ref_pos then by DESCENDING Python string order (the tie-break of AmpliPy.py:771).
- * For every position the device returns total depth, the 6 base symbols ranked like
- * sorted(..., reverse=True), and consensus / variant decisions (see amp_call_out). */
+/* ---- calling: alleles_from_counts (AmpliPy.py:756-771) + the loop AmpliPy.py:917-952 --------
+ * One device pass decides, for every reference position, everything that does not depend on
+ * the TEXT of an insertion allele: total depth (all symbols, insertion events included,
+ * :767), the six base symbols ranked like sorted(..., reverse=True) (:771), the consensus
+ * symbol (:928-929) and the variant record (:933-951).  Frequencies are IEEE doubles
+ * count/total compared with >=, exactly as Python computes them.
+ * An insertion string can only change a decision when the position's insertion events could
+ * out-rank the best base symbol or reach min_freq_variants; those positions come back with
+ * AMP_CALL_INS_RELEVANT and the host finishes them from amp_get_ins_events (the strings live
+ * in the reads: SEQ[q_from:q_to]).  full_ranking = 1 flags every position that has events. */
 typedef struct amp_call_params {
     int32_t min_depth_consensus;
     int32_t min_depth_variants;
@@ -214,31 +220,34 @@ typedef struct amp_call_params {
     double min_freq_variants;
     int32_t run_consensus;
     int32_t run_variants;
+    int32_t full_ranking;
+    int32_t reserved;
 } amp_call_params;
 
-/* One ranked allele of one position. sym: 0..5 = A C G T N '-', 6+k = k-th insertion row of
- * that position (in the order given). */
-typedef struct amp_allele {
-    uint32_t count;
-    int32_t sym;
-} amp_allele;
+#define AMP_CALL_VARIANT 1u      /* a VCF record is emitted (AmpliPy.py:940) */
+#define AMP_CALL_GT_HAS_REF 2u   /* GT starts at 0 (AmpliPy.py:948-949) */
+#define AMP_CALL_INS_RELEVANT 4u /* insertion alleles may change this position's outcome */
 
-typedef struct amp_call_out {
-    uint32_t *total_depth;   /* [ref_len] sum of all symbol counts incl. insertions (:767) */
-    int32_t *consensus_sym;  /* [ref_len] -1 = unknown symbol, else sym as in amp_allele (:928-929) */
-    int32_t *n_alleles;      /* [ref_len] number of non-zero alleles */
-    uint64_t *allele_off;    /* [ref_len+1] offsets into alleles */
-    amp_allele *alleles;     /* [alleles_cap] ranked alleles of every position, concatenated */
-    int64_t alleles_cap;
-    uint8_t *variant_flags;  /* [ref_len] bit0: record emitted (:940); bit1: GT includes 0 (:948) */
-    uint32_t *ref_count;     /* [ref_len] count of the reference symbol (:937) */
-    uint8_t *allele_flags;   /* [alleles_cap] parallel to alleles: 1 = ALT (:938-939), 2 = the REF symbol (:936) */
-} amp_call_out;
+typedef struct amp_pos_call {
+    uint32_t total_depth; /* :767 */
+    uint32_t ref_count;   /* count of the reference symbol (:937); 0 when it is not one of A C G T N - */
+    uint32_t order;       /* bits 3k..3k+2: column (A C G T N - = 0..5) of the k-th ranked base symbol;
+                             bits 18..20: number of base symbols with a non-zero count */
+    int8_t consensus_sym; /* -1 = unknown symbol, else column 0..5 of the consensus (:929) */
+    uint8_t flags;        /* AMP_CALL_* */
+    uint8_t alt_mask;     /* bit k: k-th ranked base symbol is an ALT (:938-939) */
+    uint8_t pad;
+} amp_pos_call;
 
-int amp_call(amp_ctx *ctx, const amp_call_params *params, const uint8_t *ref_seq /* ASCII [ref_len] */,
-             int64_t n_ins, const int32_t *ins_pos, const uint32_t *ins_count,
-             const uint8_t *const *ins_str, const int32_t *ins_len,
-             const amp_call_out *out /* host pointers */);
+/* ASCII reference sequence, length ref_len, exactly as read from the FASTA (REF is compared
+ * un-upper-cased, AmpliPy.py:923). */
+int amp_set_reference(amp_ctx *ctx, const uint8_t *ref_ascii);
+int amp_call_positions(amp_ctx *ctx, const amp_call_params *params, amp_pos_call *out /* host [ref_len] */,
+                       int64_t *n_relevant);
+/* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
+ * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host. */
+int amp_event_strings(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int64_t n_events,
+                      const amp_ins_event *events, const uint64_t *off, uint8_t *text);
 
 #ifdef __cplusplus
 }

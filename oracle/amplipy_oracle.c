@@ -12,7 +12,7 @@
  * kernels, which use a different decomposition.
  *
  * Pinning: tests/test_oracle_golden.py checks every function here against
- * tests/golden/*, which tools/make_golden.py produced by running the reference's own
+ * tests/golden files, which tools/make_golden.py produced by running the reference's own
  * functions.  The pysam accessor semantics (query_alignment_start/end, reference_length,
  * get_aligned_pairs) are not covered by any reference test and the
  * pysam source is not vendored: that part of the parity is UNPINNED.

@@ -135,3 +135,78 @@ def test_replication_property_full_depth(runner, scheme):
         e.process(base, read_base=0, want_trim=False)
     assert np.array_equal(e.counts(), a.counts * np.uint32(k))
     assert e.events().size == a.events.size * k
+
+
+def _golden_calls_check(runner, g, batch, do_trim, mn=None, mx=None, mpl=0):
+    from amplipy_amd import calling
+    from amplipy_amd.insertions import event_strings
+    pr = g["params"]
+    r = runner.process(batch, g["ref_len"], mn, mx, mpl, pr["min_quality"], pr.get("window", 4), do_trim=do_trim)
+    assert not r.trim.status.any()
+    assert H.sparse_from_engine(r.counts, batch, r.events) == H.sparse_from_golden(g["counts"])
+    e = runner.engine(g["ref_len"])
+    ref_seq = g.get("ref_seq") or synth.genome_string(synth.make_genome())
+    e.set_reference(ref_seq)
+    pairs = event_strings(batch, r.events)
+    provider = lambda positions: calling.tallies_from_events(pairs, positions)
+    want = {c["pos"]: c for c in g["calls"]}
+    for full in (True, False):
+        cp = calling.call_params(pr["min_depth_consensus"], pr["min_freq_consensus"], pr["min_depth_variants"],
+                                 pr["min_freq_variants"], True, True, full_ranking=full)
+        res = calling.call(e, ref_seq, cp, provider, want_alleles=full)
+        got_rec = {v.pos: v.as_dict() for v in res.records}
+        for p in range(g["ref_len"]):
+            w = want.get(p)
+            assert res.consensus[p] == (w.get("consensus") if w else None), (p, full)
+            assert got_rec.get(p) == (w.get("variant") if w else None), (p, full)
+        if full:
+            assert set(res.alleles) == set(want)
+            for p, w in want.items():
+                total, ranked = res.alleles[p]
+                assert total == w["total"]
+                assert [[c, float(f).hex(), k] for c, f, k in ranked] == w["alleles"], p
+        else:
+            assert res.n_relevant <= len(want)
+
+
+def test_calls_match_golden_trimmed(runner):
+    g = H.load_json("pileup_5000.json.gz")
+    b = ReadBatch.from_segments([H.seg_from_dict(d) for d in g["reads"]])
+    mn, mx, mpl = oracle.find_overlapping_primers(g["ref_len"], g["primers"], g["offset"])
+    _golden_calls_check(runner, g, b, True, mn, mx, mpl)
+
+
+def test_calls_match_golden_untrimmed(runner):
+    g = H.load_json("pileup_notrim_1500.json.gz")
+    reads = H.load_json("pileup_5000.json.gz")["reads"][:g["n_reads"]]
+    b = ReadBatch.from_segments([H.seg_from_dict(d) for d in reads])
+    _golden_calls_check(runner, g, b, False)
+
+
+def test_device_double_division_is_python_division(runner):
+    """The frequency thresholds compare IEEE doubles count/total; the device must agree with
+    Python on ties exactly at the threshold."""
+    from amplipy_amd import calling
+    G = 4096
+    e = runner.engine(G)
+    e.reset()
+    rng = np.random.default_rng(5)
+    counts = np.zeros((G, 6), np.uint32)
+    counts[:, 0] = rng.integers(1, 5000, size=G)      # A
+    counts[:, 1] = rng.integers(0, 5000, size=G)      # C
+    counts[:, 3] = rng.integers(0, 50, size=G)        # T
+    e.add_counts(counts)
+    ref = "A" * G
+    e.set_reference(ref)
+    tot = counts.sum(axis=1).astype(np.int64)
+    for thr_pos in (7, 100, 2222):
+        f = float(counts[thr_pos, 1]) / float(tot[thr_pos]) if counts[thr_pos, 1] else 0.25
+        cp = calling.call_params(1, f, 1, f, True, True)
+        res = calling.call(e, ref, cp, None)
+        rec = {v.pos: v for v in res.records}
+        for p in range(G):
+            alts = [s for c, s in sorted(((int(counts[p, k]), "ACGTN-"[k]) for k in range(6) if counts[p, k]), reverse=True)
+                    if s != "A" and c / int(tot[p]) >= f]
+            assert (rec[p].alts if p in rec else []) == alts, p
+            top = max(((int(counts[p, k]), "ACGTN-"[k]) for k in range(6) if counts[p, k]))
+            assert res.consensus[p] == (top[1] if top[0] / int(tot[p]) >= f else None), p
