@@ -38,11 +38,71 @@ class VariantRecord:
 
 
 class CallResult:
-    def __init__(self, consensus, records, alleles, n_relevant):
-        self.consensus = consensus      # list[str | None] per position (None = below thresholds)
-        self.records = records          # list[VariantRecord], ascending position
-        self.alleles = alleles          # {pos: (total, [(count, freq, symbol)])} when requested
+    """Columnar outcome of calling.
+
+    consensus_sym  int8[G]: -1 below thresholds, 0..5 = A C G T N '-', -2 = an insertion string
+                   (text in ``consensus_ins[pos]``)
+    var_pos        int32[V] positions with a VCF record, ascending
+    var_total / var_ref_count  uint32[V];  var_gt_ref  bool[V] (GT includes 0)
+    var_nalt       int8[V];  var_alt_col int8[V,5] (columns of the base-symbol ALTs, -1 pad);
+                   var_alt_count uint32[V,5]
+    ``extra``      {pos: VariantRecord or None} for positions finished from insertion alleles
+                   (they override the arrays; None = no record)
+    """
+
+    def __init__(self, ref_seq, consensus_sym, consensus_ins, var_pos, var_total, var_ref_count, var_gt_ref, var_nalt,
+                 var_alt_col, var_alt_count, extra, alleles, n_relevant):
+        self.ref_seq = ref_seq
+        self.consensus_sym = consensus_sym
+        self.consensus_ins = consensus_ins
+        self.var_pos, self.var_total, self.var_ref_count, self.var_gt_ref = var_pos, var_total, var_ref_count, var_gt_ref
+        self.var_nalt, self.var_alt_col, self.var_alt_count = var_nalt, var_alt_col, var_alt_count
+        self.extra = extra
+        self.alleles = alleles
         self.n_relevant = n_relevant
+        self._records = None
+
+    @property
+    def n_records(self):
+        return int(self.var_pos.size) + sum(1 for v in self.extra.values() if v is not None)
+
+    @property
+    def consensus(self):
+        """list[str | None] per position (None = below thresholds)."""
+        out = [None if c < 0 else SYMS[c] for c in self.consensus_sym.tolist()]
+        for p, s in self.consensus_ins.items():
+            out[p] = s
+        return out
+
+    def consensus_string(self, unknown_symbol="N"):
+        """''.join(consensus_symbols) of AmpliPy.py:960."""
+        lut = np.frombuffer((SYMS + unknown_symbol).encode("ascii"), np.uint8)
+        idx = np.where(self.consensus_sym >= 0, self.consensus_sym, 6).astype(np.int64)
+        if not self.consensus_ins:
+            return lut[idx].tobytes().decode("ascii")
+        parts = [chr(c) for c in lut[idx]]
+        for p, s in self.consensus_ins.items():
+            parts[p] = s
+        return "".join(parts)
+
+    @property
+    def records(self):
+        """VariantRecord objects in ascending position (materialised on demand)."""
+        if self._records is None:
+            recs = {}
+            for i, p in enumerate(self.var_pos.tolist()):
+                total = int(self.var_total[i]); rc = int(self.var_ref_count[i]); na = int(self.var_nalt[i])
+                cols = self.var_alt_col[i, :na].tolist(); cnts = [int(c) for c in self.var_alt_count[i, :na]]
+                rf = rc / total if rc else 0
+                gt = tuple(range(na + 1)) if self.var_gt_ref[i] else tuple(range(1, na + 1))
+                recs[p] = VariantRecord(p, self.ref_seq[p], [SYMS[c] for c in cols], total, rc, cnts, rf,
+                                        [c / total for c in cnts], gt)
+            for p, r in self.extra.items():
+                recs.pop(p, None)
+                if r is not None:
+                    recs[p] = r
+            self._records = [recs[p] for p in sorted(recs)]
+        return self._records
 
 
 def call_params(min_depth_consensus=10, min_freq_consensus=0.0, min_depth_variants=1, min_freq_variants=0.03,
@@ -79,70 +139,74 @@ def _decide(pos, ref_symbol, total, ranked, cp):
     return consensus, record
 
 
-def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False):
+def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False, positions=None):
     """Run calling for the state accumulated in ``engine``.
 
-    ``cp``: abi.AmpCallParams (see call_params).  ``ins_strings_at(positions) -> {pos: Counter}``
+    ``cp``: abi.AmpCallParams (see call_params).  ``ins_strings_at(positions) -> {pos: {str: n}}``
     supplies the insertion-allele tallies of the flagged positions (only called when needed).
+    ``positions``: a (records, n_relevant) pair already obtained from engine.call_positions.
     """
-    pc, n_rel = engine.call_positions(cp)
-    G = engine.ref_len
+    pc, n_rel = positions if positions is not None else engine.call_positions(cp)
+    flags = pc["flags"]
+    consensus_sym = pc["consensus_sym"].copy() if cp.run_consensus else np.full(engine.ref_len, -1, np.int8)
+    is_rel = (flags & abi.CALL_INS_RELEVANT) != 0
+    var_mask = ((flags & abi.CALL_VARIANT) != 0) & ~is_rel if cp.run_variants else np.zeros(flags.size, bool)
+    var_pos = np.nonzero(var_mask)[0].astype(np.int32)
     counts = None
-    consensus = [None] * G
-    if cp.run_consensus:
-        cs = pc["consensus_sym"]
-        for p in np.nonzero(cs >= 0)[0]:
-            consensus[int(p)] = SYMS[int(cs[p])]
-    relevant = np.nonzero(pc["flags"] & abi.CALL_INS_RELEVANT)[0]
-    rel_set = set(int(p) for p in relevant)
-    records = {}
-    alleles = {} if want_alleles else None
-    var_pos = np.nonzero(pc["flags"] & abi.CALL_VARIANT)[0] if cp.run_variants else []
-    need_counts = len(var_pos) or len(relevant) or want_alleles
-    if need_counts:
+    if var_pos.size or n_rel or want_alleles:
         counts = engine.counts()
-    for p in var_pos:
-        p = int(p)
-        if p in rel_set:
-            continue
-        rec = pc[p]
-        total = int(rec["total_depth"])
-        ranked = _ranked_bases(rec["order"], counts[p])
-        alt_s = []; alt_c = []; alt_f = []
-        for k, (c, s) in enumerate(ranked):
-            if (int(rec["alt_mask"]) >> k) & 1:
-                alt_s.append(s); alt_c.append(c); alt_f.append(c / total)
-        rc = int(rec["ref_count"])
-        rf = rc / total if rc else 0
-        gt = tuple(range(len(alt_s) + 1)) if (int(rec["flags"]) & abi.CALL_GT_HAS_REF) else tuple(range(1, len(alt_s) + 1))
-        records[p] = VariantRecord(p, ref_seq[p], alt_s, total, rc, alt_c, rf, alt_f, gt)
-    if len(relevant):
+    V = var_pos.size
+    alt_col = np.full((V, 5), -1, np.int8)
+    alt_cnt = np.zeros((V, 5), np.uint32)
+    nalt = np.zeros(V, np.int8)
+    if V:
+        order = pc["order"][var_pos]
+        am = pc["alt_mask"][var_pos]
+        for k in range(6):                    # ranked slot k -> next free ALT column
+            sel = ((am >> k) & 1).astype(bool)
+            if not sel.any():
+                continue
+            col = ((order >> (3 * k)) & 7).astype(np.int8)
+            rows = np.nonzero(sel)[0]
+            dst = nalt[rows].astype(np.int64)
+            alt_col[rows, dst] = col[rows]
+            alt_cnt[rows, dst] = counts[var_pos[rows], col[rows]]
+            nalt[rows] += 1
+    extra = {}
+    consensus_ins = {}
+    alleles = {} if want_alleles else None
+    if n_rel:
         if ins_strings_at is None:
-            raise RuntimeError("%d positions need insertion alleles but no provider was given" % len(relevant))
+            raise RuntimeError("%d positions need insertion alleles but no provider was given" % n_rel)
+        rel_set = set(int(p) for p in np.nonzero(is_rel)[0])
         tallies = ins_strings_at(rel_set)
         for p in sorted(rel_set):
             d = {SYMS[c]: int(counts[p, c]) for c in range(abi.NSYM)}
-            for s, n in tallies.get(p, {}).items():
-                d[s] = d.get(s, 0) + n
+            for s_, n in tallies.get(p, {}).items():
+                d[s_] = d.get(s_, 0) + n
             total = sum(d.values())
             assert total == int(pc[p]["total_depth"]), "insertion tally does not match the device total at %d" % p
             ranked = sorted(((d[k], d[k] / total, k) for k in d if d[k] != 0), reverse=True)
             cons, rec = _decide(p, ref_seq[p], total, ranked, cp)
-            consensus[p] = cons
-            records.pop(p, None)
-            if rec is not None:
-                records[p] = rec
+            if cons is None:
+                consensus_sym[p] = -1
+            elif len(cons) == 1 and cons in SYMS:
+                consensus_sym[p] = SYMS.index(cons)
+            else:
+                consensus_sym[p] = -2
+                consensus_ins[p] = cons
+            extra[p] = rec
             if want_alleles:
                 alleles[p] = (total, ranked)
     if want_alleles:
-        nz = np.nonzero(pc["total_depth"])[0]
-        for p in nz:
+        for p in np.nonzero(pc["total_depth"])[0]:
             p = int(p)
-            if p in alleles:
-                continue
-            total = int(pc[p]["total_depth"])
-            alleles[p] = (total, [(c, c / total, s) for c, s in _ranked_bases(pc[p]["order"], counts[p])])
-    return CallResult(consensus, [records[p] for p in sorted(records)], alleles, n_rel)
+            if p not in alleles:
+                total = int(pc[p]["total_depth"])
+                alleles[p] = (total, [(c, c / total, s_) for c, s_ in _ranked_bases(pc[p]["order"], counts[p])])
+    return CallResult(ref_seq, consensus_sym, consensus_ins, var_pos, pc["total_depth"][var_pos],
+                      pc["ref_count"][var_pos], (flags[var_pos] & abi.CALL_GT_HAS_REF) != 0, nalt, alt_col, alt_cnt,
+                      extra, alleles, n_rel)
 
 
 def tallies_from_events(events_with_strings, positions):

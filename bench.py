@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the trim + pileup + call hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--depth D]
+
+One "step" = one pass of the whole hot path over one synthetic batch that is already resident
+in HBM: reset the device table, run the trim + pileup kernels over every read of the batch
+(trimmed CIGAR / position / flags written back to HBM), [N > 1: reduce the count tables over
+RCCL], then call every reference position (device k_call + host record assembly on rank 0).
+
+Workload (config.workload): BASELINE.json's metric is quoted on a ~30 kb reference at 10k x
+depth: 29,903 nt synthetic genome, ARTIC-style 98-amplicon primer scheme, 150 bp paired reads,
+1,993,533 reads per GPU (SURVEY.md section 8(d) generator, built on the GPU with torch).  With
+N GPUs the genome's amplicons are range-partitioned by coordinate over the ranks and every rank
+holds a full-size batch of its own range (weak scaling: the job is N x 10k x deep); counts are
+stitched with one reduce of the 7 x 29,903 uint32 device table.
+
+Prints ONE JSON line on rank 0 (see the driver contract), including
+  roofline:     algorithmic bytes of the CIGAR-scan kernel / its HIP-event duration vs 8 TB/s
+  cpu_baseline: the C restatement in oracle/ timed on this host's cores on the same batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=10000, help="mean coverage per GPU (10000 -> 1,993,533 reads)")
+    ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the CPU baseline over the batch (0 = skip)")
+    ap.add_argument("--variant", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: amplipy_amd has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from amplipy_amd import abi, calling, lib, synth, synth_torch
+
+    genome = synth.make_genome()
+    primers, amps = synth.make_artic_scheme()
+    G = int(genome.size)
+    ref_seq = synth.genome_string(genome)
+    n_reads = synth.reads_for_depth(args.depth)
+    # range partition by coordinate: rank r owns a contiguous run of amplicons
+    a_lo = (amps.shape[0] * rank) // world
+    a_hi = (amps.shape[0] * (rank + 1)) // world
+    t_gen = time.time()
+    batch = synth_torch.make_amplicon_batch_device(genome, amps[a_lo:a_hi], n_reads, seed=1000 + rank, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
+    eng = lib.Engine(G, device=local_rank)
+    eng.set_kernel_variant(args.variant)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    table = torch.zeros(G * 7, dtype=torch.int32, device=dev)      # counts [G][6] + insertion tally [G]
+    eng.bind_counts(table.data_ptr())
+    eng.set_primers(mn, mx, mpl)
+    eng.set_params(20, 4, True, True)
+    eng.set_reference(ref_seq)
+    eng.reserve_events(max(1 << 20, n_reads // 4))
+    out_t = {
+        "new_pos": torch.zeros(n_reads, dtype=torch.int32, device=dev),
+        "new_ncig": torch.zeros(n_reads, dtype=torch.int32, device=dev),
+        "new_cig": torch.zeros(batch.n_cig + 3 * n_reads, dtype=torch.int32, device=dev),
+        "ref_len": torch.zeros(n_reads, dtype=torch.int32, device=dev),
+        "trim_flags": torch.zeros(n_reads, dtype=torch.uint8, device=dev),
+        "status": torch.zeros(n_reads, dtype=torch.uint8, device=dev),
+    }
+    dev_out = abi.AmpTrimOut(*[out_t[k].data_ptr() for k in ("new_pos", "new_ncig", "new_cig", "ref_len", "trim_flags", "status")])
+    rd = batch.struct()
+    cp = calling.call_params(10, 0.0, 1, 0.03, True, True)
+
+    def ins_provider(positions):
+        ev = eng.events()
+        keep = np.isin(ev["ref_pos"], np.fromiter(positions, np.int64, len(positions)))
+        strings = eng.event_strings_device(rd, ev[keep]) if keep.any() else []
+        pairs = list(zip(ev["ref_pos"][keep].tolist(), strings))
+        if dist is not None:
+            gathered = [None] * world
+            dist.gather_object(pairs, gathered if rank == 0 else None, dst=0)
+            pairs = [p for part in gathered for p in part] if rank == 0 else []
+        return calling.tallies_from_events(pairs, positions)
+
+    scan_ms = []
+    last = {}
+
+    def step():
+        eng.reset()
+        eng.process_device(rd, 0, dev_out)
+        if dist is not None:
+            dist.reduce(table, dst=0, op=dist.ReduceOp.SUM)
+        if dist is None:
+            last["call"] = res = calling.call(eng, ref_seq, cp, ins_provider)
+            last["consensus"] = res.consensus_string("N")
+        else:
+            # relevant positions need every rank's insertion events: agree on the list first
+            rel = [None]
+            if rank == 0:
+                pcs = eng.call_positions(cp)
+                rel[0] = np.nonzero(pcs[0]["flags"] & abi.CALL_INS_RELEVANT)[0].tolist()
+            dist.broadcast_object_list(rel, src=0)
+            if rank == 0:
+                last["call"] = res = calling.call(eng, ref_seq, cp, ins_provider, positions=pcs)
+                last["consensus"] = res.consensus_string("N")
+            elif rel[0]:
+                ins_provider(set(rel[0]))
+        scan_ms.append(eng.last_kernel_ms()[1])
+
+    for _ in range(args.warmup):
+        step()
+    del scan_ms[:]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- accounting (outside the timed region) ------------------------------------------------
+    n_out = int(out_t["new_ncig"].sum().item())
+    n_err = int((out_t["status"] != 0).sum().item())
+    L = 150
+    alg_bytes = n_reads * (16 + (L + 1) // 2 + L + 8) + 4 * batch.n_cig + 4 * n_out + 6 * G * 4 + 2 * G * 4
+    k_ms = float(np.mean(scan_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.isfile(tf):
+        traffic = json.load(open(tf)).get("depth%d" % args.depth)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_passes > 0:
+        from oracle import oracle
+        hb = batch.to_host()
+        t_cpu = time.perf_counter()
+        for _ in range(args.cpu_passes):
+            ref = oracle.process(hb, G, mn, mx, mpl, 20, 4)
+        t_cpu = time.perf_counter() - t_cpu
+        # the checker: the GPU result of the last step must equal the oracle's on the same batch
+        got = table.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:G * 6].reshape(G, 6), ref.counts), "GPU count table differs from the oracle"
+        assert np.array_equal(out_t["new_pos"].cpu().numpy(), ref.trim.new_pos), "trimmed positions differ from the oracle"
+        assert int(got[G * 6:].sum()) == ref.events.size, "insertion events differ from the oracle"
+        cpu = {"value": round(hb.n * args.cpu_passes / t_cpu, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "the full %d-read batch, %d passes of oracle/amplipy_oracle.c (trim + pileup), 1 thread"
+                         % (hb.n, args.cpu_passes)}
+
+    if rank == 0:
+        total_reads = n_reads * world * args.steps
+        res = last["call"]
+        line = {
+            "metric": "aligned reads/s through trim+pileup+call, 30 kb ref @ 10k x depth",
+            "value": round(total_reads / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": "synthetic 29,903 nt genome, 98-amplicon ARTIC-style primers, 150 bp paired reads, "
+                                   "%d x depth = %d reads per GPU, inputs resident in HBM" % (args.depth, n_reads),
+                       "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
+                       "parallelism": "coordinate-range partition x%d + RCCL reduce of the count table" % world,
+                       "kernel_variant": args.variant, "error_reads": n_err,
+                       "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant},
+            "roofline": {"bound": "hbm", "kernel": "k_tile" if args.variant == 2 else "k_reads_lane",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 5)},
+            "cpu_baseline": cpu,
+            "gen_seconds": round(t_gen, 2),
+        }
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,9 +155,11 @@ def _golden_calls_check(runner, g, batch, do_trim, mn=None, mx=None, mpl=0):
                                  pr["min_freq_variants"], True, True, full_ranking=full)
         res = calling.call(e, ref_seq, cp, provider, want_alleles=full)
         got_rec = {v.pos: v.as_dict() for v in res.records}
+        cons = res.consensus
+        assert res.consensus_string("N") == "".join(c if c is not None else "N" for c in cons)
         for p in range(g["ref_len"]):
             w = want.get(p)
-            assert res.consensus[p] == (w.get("consensus") if w else None), (p, full)
+            assert cons[p] == (w.get("consensus") if w else None), (p, full)
             assert got_rec.get(p) == (w.get("variant") if w else None), (p, full)
         if full:
             assert set(res.alleles) == set(want)
@@ -204,9 +206,10 @@ def test_device_double_division_is_python_division(runner):
         cp = calling.call_params(1, f, 1, f, True, True)
         res = calling.call(e, ref, cp, None)
         rec = {v.pos: v for v in res.records}
+        cons = res.consensus
         for p in range(G):
             alts = [s for c, s in sorted(((int(counts[p, k]), "ACGTN-"[k]) for k in range(6) if counts[p, k]), reverse=True)
                     if s != "A" and c / int(tot[p]) >= f]
             assert (rec[p].alts if p in rec else []) == alts, p
             top = max(((int(counts[p, k]), "ACGTN-"[k]) for k in range(6) if counts[p, k]))
-            assert res.consensus[p] == (top[1] if top[0] / int(tot[p]) >= f else None), p
+            assert cons[p] == (top[1] if top[0] / int(tot[p]) >= f else None), p
