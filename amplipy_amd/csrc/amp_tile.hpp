@@ -1,8 +1,9 @@
 // amp_tile.hpp -- the fused trim + pileup kernel (variant 2), written for CDNA4 / gfx950.
 //
 // Work decomposition (nothing like the reference's per-read Python loop, A:896-915):
-//   * a wave owns a TILE of 64 consecutive reads; a block of T_WAVES waves walks a contiguous
-//     range of tiles of the coordinate-sorted batch, so it touches a bounded reference window
+//   * a wave owns a TILE of 64 consecutive reads; a block of T_WAVES waves (one block per CU)
+//     walks a contiguous range of tiles of the coordinate-sorted batch, so it touches a bounded
+//     reference window
 //   * per-position counters are PRIVATISED in LDS: win[6][W] uint32 for reference positions
 //     [win_base, win_base+W); lanes add with LDS atomics (ds_add_u32) and the block flushes
 //     the non-zero counters with global atomics when the window has to move / at the end.
@@ -10,21 +11,23 @@
 //     on the input order -- only the speed does.
 //   * the tile alternates between two lane mappings:
 //       lane = read   P1  primer clips on the CIGAR held in LDS (one column per lane)
-//                     P3  quality clip, outputs, classification, deletions / insertion events
-//       lane = chunk  P2  sliding-window quality scan: 8 aligned bases per lane, window sums
-//                         from a 16-byte neighbourhood, first failing window per read by
-//                         LDS atomicMin/Max
-//                     P4  base counting: 8 bases per lane (8 B of qual + 4 B of packed seq,
-//                         coalesced), one LDS atomic per counted base.  The base order inside
-//                         a chunk is rotated per lane so that the 32 lanes serviced together
-//                         hit 32 different banks.
-//   The match/mismatch bases of "regular" reads (clips only at the ends, body of M/=/X/I/D/N)
-//   are counted by the chunk lanes; their deletions and insertion events are handled by the
-//   read lane with a skip-ahead version of the exact pair walk.
+//                     P3  quality clip (partial windows + CIGAR rewrite), outputs, match-op
+//                         SEGMENTS, deletions / insertion events
+//       lane = chunk  P2  sliding-window quality scan: a chunk is 8 consecutive window START
+//                         positions; eight W-byte sums (v_sad_u8) from a 16-byte neighbourhood,
+//                         first / last failing full window per read by one LDS atomicMin
+//                     P4  base counting: a chunk is 8 bases of one match-op segment (8 B of
+//                         qual + 4 B of packed seq, coalesced); straight-line code, one
+//                         unconditional LDS add of 0/1 per base.  The base order inside a chunk
+//                         is rotated per lane so that the 32 lanes serviced together hit 32
+//                         different banks.
+//     Chunk lanes find their owner through a byte map in LDS that the read lanes fill
+//     (chunk -> read for P2, chunk -> segment for P4); the map aliases the spare CIGAR buffer.
 //   * anything unusual is DEFERRED to the lane-per-read kernel (k_reads_deferred in
 //     amplihip.hip), which runs the exact serial code of amp_read.hpp: reads with more CIGAR
 //     ops than the LDS columns hold, reads of 64 k bases or more, reads whose trimmed CIGAR is
-//     not regular, and (status only) regular reads on which a chunk lane met an error.
+//     not regular (clips only at the ends, body of M/=/X/I/D/N), reads whose segments do not
+//     fit the tile's segment table, and (status only) reads on which a chunk lane met an error.
 #pragma once
 
 #include "amp_read.hpp"
@@ -32,29 +35,32 @@
 namespace amp {
 
 constexpr int TILE = 64;          // reads per wave tile
-constexpr int T_WAVES = 8;        // waves per block
+constexpr int T_WAVES = 16;       // waves per block (one block per CU)
 constexpr int T_W = 1024;         // reference positions covered by the LDS window
 constexpr int T_MAXOPS = 8;       // CIGAR ops per read held in LDS (input ops <= T_MAXOPS-3)
+constexpr int T_MAPCAP = T_MAXOPS * TILE * 4;   // chunk-map bytes = the spare CIGAR buffer
+constexpr int T_SEGCAP = 128;     // match-op segments per tile
 constexpr int32_t NO_WINDOW = INT32_MIN;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 // entries of the deferred list: read index | kind
 constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;
 
 // per-read state words kept in LDS for the chunk lanes
-enum : int { S_POS, S_CB2, S_CB4, S_OFF8, S_LOHI, S_M, S_FF, S_INFO, S_WORDS };
-// S_INFO bits
-constexpr uint32_t I_REV = 1u, I_SIMPLE = 2u, I_NOCHUNK = 4u, I_ERRFLAG = 8u, I_INB = 16u;
-constexpr int I_NCIG_SHIFT = 8;
+enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_WORDS };
+enum : int { G_OFF8, G_M, G_R0, G_READ, G_CB, G_WORDS };   // per-segment words
 
 struct WaveLds {
     uint32_t cigA[T_MAXOPS * TILE];
-    uint32_t cigB[T_MAXOPS * TILE];
+    uint32_t cigB[T_MAXOPS * TILE];   // scratch during trimming, chunk map during P2 / P4
     uint32_t st[S_WORDS * TILE];
+    uint32_t seg[G_WORDS * T_SEGCAP];
 };
 struct BlockLds {
     uint32_t win[AMP_NSYM * T_W];
+    uint32_t lut[16];                 // BAM base code -> byte offset of its count plane
     WaveLds wv[T_WAVES];
 };
 
@@ -71,8 +77,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void lds_inc(lds_u32 *p) {
-    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void lds_add(lds_u32 *p, uint32_t v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 struct TileCtx {
@@ -86,7 +92,7 @@ struct TileCtx {
 
 __device__ __forceinline__ void tile_add(const TileCtx &t, int32_t r, uint32_t col) {
     uint32_t d = (uint32_t)(r - t.win_base);
-    if (d < (uint32_t)T_W) lds_inc(t.win + col * T_W + d);
+    if (d < (uint32_t)T_W) lds_add(t.win + col * T_W + d, 1u);
     else atomicAdd(&t.counts[(size_t)r * AMP_NSYM + col], 1u);
 }
 
@@ -165,15 +171,63 @@ __device__ int count_regular_skip(const KParams &P, const CB &cig, int n, int32_
     return 0;
 }
 
+// A(1) C(2) G(4) T(8) -> 0..3, N(15) -> 4, anything else -> 15
+__device__ __forceinline__ uint32_t col_of_code(uint32_t code) {
+    const uint32_t lo = 0xFFF2F10Fu;  // codes 0..7
+    const uint32_t hi = 0x4FFFFFF3u;  // codes 8..15
+    uint32_t x = (code & 8u) ? hi : lo;
+    return (x >> ((code & 7u) * 4u)) & 15u;
+}
+
+// sum of the W bytes starting at byte `b` (0..7) of the 16-byte group w[0..3]
+template <int W>
+__device__ __forceinline__ uint32_t window_sum_at(const uint32_t (&w)[4], int b) {
+    const int d = b >> 2, sh = (b & 3) * 8;
+    uint32_t x = sh ? __builtin_amdgcn_alignbit(w[d + 1], w[d], sh) : w[d];
+    if (W <= 4) {
+        if (W < 4) x &= (1u << (W * 8)) - 1u;
+        return __builtin_amdgcn_sad_u8(x, 0u, 0u);
+    }
+    uint32_t y = sh ? __builtin_amdgcn_alignbit(d + 2 < 4 ? w[d + 2] : 0u, w[d + 1], sh) : w[d + 1];
+    if (W < 8) y &= (1u << ((W - 4) * 8)) - 1u;
+    return __builtin_amdgcn_sad_u8(y, 0u, __builtin_amdgcn_sad_u8(x, 0u, 0u));
+}
+
+// bit b set: the W-byte window starting at byte b of w[] sums to less than thr
+template <int W>
+__device__ __forceinline__ uint32_t window_fail_bits(const uint32_t (&w)[4], uint32_t thr) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) m |= (window_sum_at<W>(w, b) < thr ? 1u : 0u) << b;
+    return m;
+}
+
+__device__ __forceinline__ uint32_t window_fail_bits_dyn(int Wd, const uint32_t (&w)[4], uint32_t thr) {
+    switch (Wd) {
+        case 1: return window_fail_bits<1>(w, thr); case 2: return window_fail_bits<2>(w, thr);
+        case 3: return window_fail_bits<3>(w, thr); case 4: return window_fail_bits<4>(w, thr);
+        case 5: return window_fail_bits<5>(w, thr); case 6: return window_fail_bits<6>(w, thr);
+        case 7: return window_fail_bits<7>(w, thr); default: return window_fail_bits<8>(w, thr);
+    }
+}
+
+// exclusive prefix sum over the 64 lanes; total in every lane
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t &total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
 // Classification of a final CIGAR.  regular: H* S* (M|=|X|I|D|N)* S* H* with query length ==
-// lseq; simple: regular and the body holds match ops only, so query bases [m0, m1) map to
-// reference positions ref_start + (q - m0).  For non-simple reads [m0, m1) spans from the
-// first to the last match base.
+// lseq.  nseg = number of match ops; plain = regular with no I/D/N at all.
 template <class CB>
-__device__ void classify(const CB &c, int n, int32_t lseq, bool &regular, bool &simple, int32_t &m0, int32_t &m1) {
+__device__ void classify(const CB &c, int n, int32_t lseq, bool &regular, bool &plain, int &nseg) {
     int phase = 0;  // 0 lead H, 1 lead S, 2 body, 3 trail S, 4 trail H
-    int32_t q = 0, nm = 0, nother = 0;
-    regular = true; m0 = m1 = 0;
+    int32_t q = 0;
+    int nother = 0;
+    regular = true; nseg = 0;
     for (int i = 0; i < n; ++i) {
         uint32_t v = c.get(i), op = v & 15u;
         int32_t len = (int32_t)(v >> 4);
@@ -188,84 +242,22 @@ __device__ void classify(const CB &c, int n, int32_t lseq, bool &regular, bool &
         } else if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_D || op == OP_N) {
             if (phase > 2) { regular = false; break; }
             phase = 2;
-            if (is_match_op(op)) {
-                if (nm++ == 0) m0 = q;
-                q += len;
-                m1 = q;
-            } else {
-                ++nother;
-                if (op == OP_I) q += len;
-            }
+            if (is_match_op(op)) { ++nseg; q += len; }
+            else { ++nother; if (op == OP_I) q += len; }
         } else {
             regular = false; break;
         }
     }
     if (q != lseq) regular = false;
-    simple = regular && nother == 0;
-}
-
-// A(1) C(2) G(4) T(8) -> 0..3, N(15) -> 4, anything else -> 15
-__device__ __forceinline__ uint32_t col_of_code(uint32_t code) {
-    const uint32_t lo = 0xFFF2F10Fu;  // codes 0..7
-    const uint32_t hi = 0x4FFFFFF3u;  // codes 8..15
-    uint32_t x = (code & 8u) ? hi : lo;
-    return (x >> ((code & 7u) * 4u)) & 15u;
-}
-
-// bytes of a dword that lie in [kmin, kmax) when the dword holds byte indices [base, base+4)
-__device__ __forceinline__ uint32_t byte_range_mask(int32_t kmin, int32_t kmax, int32_t base) {
-    int32_t a = kmin - base, b = kmax - base;
-    a = a < 0 ? 0 : (a > 4 ? 4 : a);
-    b = b < 0 ? 0 : (b > 4 ? 4 : b);
-    uint32_t ma = a >= 4 ? 0xFFFFFFFFu : ((1u << (a * 8)) - 1u);
-    uint32_t mb = b >= 4 ? 0xFFFFFFFFu : ((1u << (b * 8)) - 1u);
-    return mb & ~ma;
-}
-
-// sum of the W bytes starting at byte `b` (0..7) of the 16-byte group w[0..3]
-template <int W>
-__device__ __forceinline__ uint32_t window_sum_at(const uint32_t (&w)[4], int b) {
-    // 8 bytes starting at byte b
-    const int d = b >> 2, sh = (b & 3) * 8;
-    uint32_t x = sh ? __builtin_amdgcn_alignbit(w[d + 1], w[d], sh) : w[d];
-    if (W <= 4) {
-        if (W < 4) x &= (1u << (W * 8)) - 1u;
-        return __builtin_amdgcn_sad_u8(x, 0u, 0u);
-    }
-    uint32_t y = sh ? __builtin_amdgcn_alignbit(d + 2 < 4 ? w[d + 2] : 0u, w[d + 1], sh) : w[d + 1];
-    if (W < 8) y &= (1u << ((W - 4) * 8)) - 1u;
-    return __builtin_amdgcn_sad_u8(y, 0u, __builtin_amdgcn_sad_u8(x, 0u, 0u));
-}
-
-template <int W>
-__device__ __forceinline__ void window_sums8(const uint32_t (&w)[4], uint32_t (&s)[8]) {
-#pragma unroll
-    for (int b = 0; b < 8; ++b) s[b] = window_sum_at<W>(w, b);
-}
-
-__device__ __forceinline__ void window_sums8_dyn(int Wd, const uint32_t (&w)[4], uint32_t (&s)[8]) {
-    switch (Wd) {
-        case 1: window_sums8<1>(w, s); break; case 2: window_sums8<2>(w, s); break;
-        case 3: window_sums8<3>(w, s); break; case 4: window_sums8<4>(w, s); break;
-        case 5: window_sums8<5>(w, s); break; case 6: window_sums8<6>(w, s); break;
-        case 7: window_sums8<7>(w, s); break; default: window_sums8<8>(w, s); break;
-    }
-}
-
-__device__ __forceinline__ int find_read(const lds_u32 *cb, uint32_t c, float inv) {
-    int r = (int)((float)c * inv);
-    r = r > 63 ? 63 : r;
-    while (c < cb[r]) --r;
-    while (r < 63 && c >= cb[r + 1]) ++r;
-    return r;
+    plain = regular && nother == 0;
 }
 
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(T_WAVES * 64)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
        int tiles_per_block, uint32_t phases) {
-    unsigned long long *const ctr = eb.ctr;
     __shared__ BlockLds L;
+    unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t n = rd.n_reads;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
@@ -274,13 +266,19 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     if (tile_begin >= tile_end) return;
 
     lds_u32 *const win = (lds_u32 *)L.win;
+    lds_u32 *const lut = (lds_u32 *)L.lut;
     for (int i = tid; i < AMP_NSYM * T_W; i += T_WAVES * 64) win[i] = 0;
+    if (tid < 16) { uint32_t c = col_of_code((uint32_t)tid); lut[tid] = c <= 4u ? c * (uint32_t)(T_W * 4) : 0u; }
     int32_t win_base = NO_WINDOW;
     lds_u32 *const st = (lds_u32 *)L.wv[wave].st;
+    lds_u32 *const seg = (lds_u32 *)L.wv[wave].seg;
     lds_u32 *const cigA = (lds_u32 *)L.wv[wave].cigA;
     lds_u32 *const cigB = (lds_u32 *)L.wv[wave].cigB;
+    lds_u8 *const cmap = (lds_u8 *)L.wv[wave].cigB;
     TileCtx tc{win, 0, 0u, counts, eb, (uint32_t)P.ref_len};
     const int32_t mq = P.min_quality;
+    const int32_t Wd = P.window;
+    const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);          // sums of W bytes never reach 256*W
     unsigned long long n_err = 0;
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
@@ -325,6 +323,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         bool defer_full = valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
         const bool mine = valid && !defer_full;
         const bool have_qual = mine && lseq > 0 && qual[0] != 0xFF;
+        const bool rev = (flag & 0x10u) != 0;
         TrimState ts{pos, ncig, 0u, 0};
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
@@ -334,105 +333,89 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (P.do_trim) {
                 trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
                 if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);
-            }
-        }
-        const bool rev = (flag & 0x10u) != 0;
-        uint32_t nch2 = (mine && can_q) ? (uint32_t)(((lo + qlen + 7) >> 3) - (lo >> 3)) : 0u;
-        uint32_t incl = nch2;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const uint32_t total2 = __shfl(incl, 63);
-        st[S_CB2 * TILE + lane] = incl - nch2;
-        st[S_LOHI * TILE + lane] = (uint32_t)lo | ((uint32_t)(lo + qlen) << 16);
-        st[S_OFF8 * TILE + lane] = off8;
-        st[S_FF * TILE + lane] = rev ? 0u : (uint32_t)qlen;
-        st[S_INFO * TILE + lane] = (rev ? I_REV : 0u);
-        wave_sync();
-
-        // =================================== P2: lane = chunk ===================================
-        if (P.do_trim && (phases & 2u)) {
-            const float inv2 = total2 ? 64.0f / (float)total2 : 0.0f;
-            const int32_t Wd = P.window;
-            for (uint32_t c = lane; c < total2; c += 64) {
-                const int r = find_read(st + S_CB2 * TILE, c, inv2);
-                const uint32_t lohi = st[S_LOHI * TILE + r];
-                const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
-                const int32_t j0 = ((int32_t)(c - st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
-                const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8;
-                const bool rrev = st[S_INFO * TILE + r] & I_REV;
-                if (Wd <= 8) {
-                    // 16-byte neighbourhood: [j0-8, j0+8) for reverse reads, [j0, j0+16) for forward
-                    const int32_t a0 = rrev ? j0 - 8 : j0;
-                    uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
-                    if (a0 >= 0) w0 = *(const uint2 *)(qp + a0);
-                    if (a0 + 8 < rhi) w1 = *(const uint2 *)(qp + a0 + 8);
-                    // zero the bytes outside [rlo, rhi)
-                    const int32_t kmin = rlo - a0, kmax = rhi - a0;
-                    uint32_t w[4] = {w0.x, w0.y, w1.x, w1.y};
-                    if (kmin > 0 || kmax < 16) {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) w[d] &= byte_range_mask(kmin, kmax, d * 4);
-                    }
-                    uint32_t s[8];
-                    if (rrev) {
-                        // mirror the 16 bytes so that the window of a base runs towards higher indices:
-                        // mirrored byte k = base a0+15-k; base j0+7-bb is mirrored byte bb
-                        uint32_t m[4];
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) m[d] = __builtin_bswap32(w[3 - d]);
-                        window_sums8_dyn(Wd, m, s);
-                        int32_t best = 0;
-#pragma unroll
-                        for (int bb = 7; bb >= 0; --bb) {
-                            const int32_t a = j0 + 7 - bb;          // last base of the window
-                            const int32_t iend = a + 1 - rlo;       // the reference's loop variable i
-                            const int32_t wl_ = iend < Wd ? iend : Wd;
-                            if (a >= rlo && a < rhi && (int32_t)s[bb] < mq * wl_) best = iend;
-                        }
-                        if (best) __hip_atomic_fetch_max(st + S_FF * TILE + r, (uint32_t)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
-                        window_sums8_dyn(Wd, w, s);
-                        int32_t best = -1;
-#pragma unroll
-                        for (int bb = 7; bb >= 0; --bb) {
-                            const int32_t a = j0 + bb;
-                            const int32_t left = rhi - a;
-                            const int32_t wl_ = left < Wd ? left : Wd;
-                            if (a >= rlo && a < rhi && (int32_t)s[bb] < mq * wl_) best = a - rlo;
-                        }
-                        if (best >= 0) __hip_atomic_fetch_min(st + S_FF * TILE + r, (uint32_t)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                } else {
-                    // wide windows: direct sums from global memory (rare parameter choice)
-                    for (int bb = 0; bb < 8; ++bb) {
-                        const int32_t a = j0 + bb;
-                        if (a < rlo || a >= rhi) continue;
-                        if (rrev) {
-                            const int32_t iend = a + 1 - rlo;
-                            const int32_t wl_ = iend < Wd ? iend : Wd;
-                            int64_t sum = 0;
-                            for (int32_t k = 0; k < wl_; ++k) sum += qp[a - k];
-                            if (sum < (int64_t)mq * wl_) __hip_atomic_fetch_max(st + S_FF * TILE + r, (uint32_t)iend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
-                            const int32_t left = rhi - a;
-                            const int32_t wl_ = left < Wd ? left : Wd;
-                            int64_t sum = 0;
-                            for (int32_t k = 0; k < wl_; ++k) sum += qp[a + k];
-                            if (sum < (int64_t)mq * wl_) __hip_atomic_fetch_min(st + S_FF * TILE + r, (uint32_t)(a - rlo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
+                if (cur.p != cigA + lane) {           // keep the CIGAR in buffer A: B becomes the chunk map
+                    for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = cur.get(k);
+                    cur.p = cigA + lane; tmp.p = cigB + lane;
                 }
             }
-            wave_sync();
         }
+        // full windows start at aligned-quality indices [0, qlen - W]; chunks are 8 starts wide
+        const bool par_scan = mine && can_q && Wd <= 8 && (phases & 2u);
+        const int32_t hi = lo + qlen;
+        uint32_t nch2 = 0;
+        if (par_scan && qlen >= Wd) nch2 = (uint32_t)(((hi - Wd) >> 3) - (lo >> 3) + 1);
+        uint32_t total2;
+        const uint32_t cb2 = wave_excl_scan(nch2, lane, total2);
+        st[S_OFF8 * TILE + lane] = off8;
+        st[S_LOHI * TILE + lane] = (uint32_t)lo | ((uint32_t)hi << 16);
+        st[S_FF * TILE + lane] = 0xFFFFu;
+        st[S_REV * TILE + lane] = rev ? 1u : 0u;
+        st[S_ERR * TILE + lane] = 0u;
+        st[S_CB2 * TILE + lane] = cb2;
+
+        // =================================== P2: lane = chunk ===================================
+        for (uint32_t base = 0; base < total2; base += T_MAPCAP) {
+            wave_sync();
+            {   // read lanes publish chunk -> read for this round
+                uint32_t a = cb2 > base ? cb2 : base, b = cb2 + nch2 < base + T_MAPCAP ? cb2 + nch2 : base + T_MAPCAP;
+                for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)lane;
+            }
+            wave_sync();
+            const uint32_t lim = total2 - base < (uint32_t)T_MAPCAP ? total2 - base : (uint32_t)T_MAPCAP;
+            for (uint32_t c = lane; c < lim; c += 64) {
+                const uint32_t r = cmap[c];
+                const uint32_t lohi = st[S_LOHI * TILE + r];
+                const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
+                const uint32_t rcb = st[S_CB2 * TILE + r];
+                const int32_t j0 = ((int32_t)(c + base - rcb) + (rlo >> 3)) * 8;
+                const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8 + j0;
+                const uint2 w0 = *(const uint2 *)qp;
+                uint2 w1 = make_uint2(0, 0);
+                if (j0 + 8 < rhi) w1 = *(const uint2 *)(qp + 8);
+                const uint32_t w[4] = {w0.x, w0.y, w1.x, w1.y};
+                uint32_t fail = window_fail_bits_dyn(Wd, w, mqc * (uint32_t)Wd);
+                // starts j0+b must lie in [rlo, rhi - W]
+                int32_t blo = rlo - j0, bhi = rhi - Wd - j0;
+                blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
+                fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
+                if (fail) {
+                    uint32_t v;
+                    if (st[S_REV * TILE + r]) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
+                    else v = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);                                 // first failing window start
+                    __hip_atomic_fetch_min(st + S_FF * TILE + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        wave_sync();
 
         // =================================== P3: lane = read ===================================
         int cerr = 0;
-        bool chunks = false, simple = false;
-        int32_t m0 = 0, m1 = 0;
+        int nseg = 0;
+        bool counted = false;
         if (mine && !ts.err && P.do_trim && can_q) {
-            const int32_t ff = (int32_t)st[S_FF * TILE + lane];
-            trim_quality_apply(ts, rev, ff, qlen, qs, cur, tmp);
+            int32_t iq;
+            if (par_scan) {
+                const uint32_t v = st[S_FF * TILE + lane];
+                if (v != 0xFFFFu) {
+                    iq = rev ? (int32_t)(0xFFFFu - v) : (int32_t)v;
+                } else {
+                    // no full window failed: the shrinking windows at the 3' end decide (A:575-576, A:637-638)
+                    const uint8_t *q = qual + lo;
+                    iq = rev ? 0 : qlen;
+                    int32_t acc = 0;
+                    for (int32_t k = 1; k < Wd && k <= qlen; ++k) {
+                        acc += rev ? q[k - 1] : q[qlen - k];
+                        if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
+                    }
+                }
+            } else {
+                iq = quality_scan(qual + lo, qlen, Wd, mq, rev);
+            }
+            trim_quality_apply(ts, rev, iq, qlen, qs, cur, tmp);
+            if (!ts.err && cur.p != cigA + lane) {
+                for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = cur.get(k);
+                cur.p = cigA + lane; tmp.p = cigB + lane;
+            }
         }
         if (mine) {
             int32_t reflen = 0;
@@ -446,125 +429,141 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (out.ref_len) out.ref_len[i] = ts.err ? 0 : reflen;
             if (out.trim_flags) out.trim_flags[i] = ts.err ? (uint8_t)0 : (uint8_t)ts.flags;
         }
+        bool plain = false;
+        int32_t fqs = 0, fqe = 0;
         if (mine && !ts.err && P.do_count) {
             bool regular;
-            classify(cur, ts.n, lseq, regular, simple, m0, m1);
+            classify(cur, ts.n, lseq, regular, plain, nseg);
             if (!have_qual) regular = false;
             int e1 = 0, e2 = 0;
-            int32_t fqs = 0, fqe = 0;
             if (regular) { fqs = query_alignment_start(cur, ts.n, lseq, e1); fqe = query_alignment_end(cur, ts.n, lseq, e2); }
-            if (!regular || e1 || e2) {
-                defer_full = true;
-            } else {
-                chunks = m1 > m0;
-                if (!simple && (phases & 8u)) {
-                    TileSink sink{tc, (uint32_t)(read_base + (uint64_t)i)};
-                    cerr = count_regular_skip(P, cur, ts.n, ts.pos, lseq, fqs, fqe, qual, sink);
-                }
+            if (!regular || e1 || e2) { defer_full = true; nseg = 0; }
+            else counted = true;
+        }
+        // segments: one per match op, allotted by a wave scan; a read that does not fit is deferred
+        uint32_t total_seg;
+        uint32_t sb = wave_excl_scan((uint32_t)nseg, lane, total_seg);
+        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }
+        uint32_t nch4 = 0;
+        if (counted) {
+            int32_t q = 0, r = ts.pos;
+            uint32_t sidx = sb;
+            for (int k = 0; k < ts.n; ++k) {
+                uint32_t v = cur.get(k), op = v & 15u;
+                int32_t len = (int32_t)(v >> 4);
+                if (is_match_op(op)) {
+                    if (len > 0) {
+                        seg[G_OFF8 * T_SEGCAP + sidx] = off8;
+                        seg[G_M * T_SEGCAP + sidx] = (uint32_t)q | ((uint32_t)(q + len) << 16);
+                        seg[G_R0 * T_SEGCAP + sidx] = (uint32_t)r;
+                        seg[G_READ * T_SEGCAP + sidx] = (uint32_t)lane;
+                        nch4 += (uint32_t)(((q + len + 7) >> 3) - (q >> 3));
+                    } else {
+                        seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_OFF8 * T_SEGCAP + sidx] = off8; seg[G_R0 * T_SEGCAP + sidx] = 0u;
+                        seg[G_READ * T_SEGCAP + sidx] = (uint32_t)lane;
+                    }
+                    ++sidx;
+                    q += len; r += len;
+                } else if (op == OP_I || op == OP_S) q += len;
+                else if (op == OP_D || op == OP_N) r += len;
+            }
+            if (!plain && (phases & 8u)) {
+                TileSink sink{tc, (uint32_t)(read_base + (uint64_t)i)};
+                cerr = count_regular_skip(P, cur, ts.n, ts.pos, lseq, fqs, fqe, qual, sink);
             }
         }
-        uint32_t nch4 = chunks ? (uint32_t)(((m1 + 7) >> 3) - (m0 >> 3)) : 0u;
-        incl = nch4;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const uint32_t total4 = __shfl(incl, 63);
-        st[S_CB4 * TILE + lane] = incl - nch4;
-        st[S_M * TILE + lane] = (uint32_t)m0 | ((uint32_t)m1 << 16);
-        st[S_POS * TILE + lane] = (uint32_t)ts.pos;
-        st[S_INFO * TILE + lane] = (simple ? I_SIMPLE : 0u) | ((cur.p != cigA + lane) ? I_INB : 0u) | ((uint32_t)ts.n << I_NCIG_SHIFT);
-        wave_sync();
+        if (!(phases & 4u)) nch4 = 0;
+        uint32_t total4;
+        const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
 
         // =================================== P4: lane = chunk ===================================
-        if (P.do_count && (phases & 4u)) {
-            const float inv4 = total4 ? 64.0f / (float)total4 : 0.0f;
-            for (uint32_t c = lane; c < total4; c += 64) {
-                const int r = find_read(st + S_CB4 * TILE, c, inv4);
-                const uint32_t rinfo = st[S_INFO * TILE + r];
-                const uint32_t mm = st[S_M * TILE + r];
-                const int32_t rm0 = (int32_t)(mm & 0xFFFFu), rm1 = (int32_t)(mm >> 16);
-                const int32_t j0 = ((int32_t)(c - st[S_CB4 * TILE + r]) + (rm0 >> 3)) * 8;
-                const int64_t rb = (int64_t)st[S_OFF8 * TILE + r] * 8;
-                const uint2 qw = *(const uint2 *)(rd.qual + rb + j0);
-                uint32_t sw = *(const uint32_t *)(rd.seq + ((rb + j0) >> 1));
-                const int32_t rpos = (int32_t)st[S_POS * TILE + r];
-                bool bad = false;
-                if (rinfo & I_SIMPLE) {
-                    // rotate the 8 bases by `rot` so that lanes serviced together spread over banks
-                    const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
-                    uint32_t qa = (rot & 4u) ? qw.y : qw.x, qb = (rot & 4u) ? qw.x : qw.y;
-                    const uint32_t sh = (rot & 3u) * 8u;
-                    const uint32_t q0w = __builtin_amdgcn_alignbit(qb, qa, sh);   // bytes rot..rot+3
-                    const uint32_t q1w = __builtin_amdgcn_alignbit(qa, qb, sh);   // bytes rot+4..rot+7 (mod 8)
-                    sw = ((sw & 0x0F0F0F0Fu) << 4) | ((sw >> 4) & 0x0F0F0F0Fu);   // base k at bits [4k, 4k+4)
-                    sw = __builtin_amdgcn_alignbit(sw, sw, rot * 4u);
-                    const int32_t d0 = rpos + (j0 - rm0) - win_base;               // window offset of base 0
-                    const uint32_t span = (uint32_t)(rm1 - rm0);
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t bb = ((uint32_t)b + rot) & 7u;
-                        const uint32_t qv = ((b < 4 ? q0w : q1w) >> ((b & 3) * 8)) & 0xFFu;
-                        const uint32_t code = (sw >> (b * 4)) & 15u;
-                        const uint32_t qrel = (uint32_t)(j0 - rm0) + bb;
-                        if (qrel < span && (int32_t)qv >= mq) {
-                            const uint32_t col = col_of_code(code);
-                            const uint32_t d = (uint32_t)d0 + bb;
-                            if (col > 4u) bad = true;
-                            else if (d < tc.wlim) lds_inc(win + col * T_W + d);
-                            else {
-                                const int32_t rp = win_base + (int32_t)d;
-                                if ((uint32_t)rp >= tc.G) bad = true;
-                                else atomicAdd(&counts[(size_t)rp * AMP_NSYM + col], 1u);
-                            }
-                        }
-                    }
-                } else {
-                    // walk the read's ops to the chunk, then base by base
-                    const int ncg = (int)(rinfo >> I_NCIG_SHIFT);
-                    LdsCig cg{((rinfo & I_INB) ? cigB : cigA) + r};
-                    int k = 0;
-                    int32_t qq = 0, rr = rpos, oplen = 0, opq = 0;
-                    uint32_t op = OP_H;
-                    for (; k < ncg; ++k) {
-                        uint32_t v = cg.get(k); op = v & 15u; oplen = (int32_t)(v >> 4);
-                        if (op == OP_H) { oplen = 0; continue; }
-                        if (consumes_query(op)) {
-                            if (j0 < qq + oplen) { opq = qq; break; }
-                            qq += oplen;
-                        }
-                        if (consumes_ref(op)) rr += oplen;
-                    }
-                    if (k < ncg) {
-                        int32_t q = j0;
-                        if (consumes_ref(op)) rr += q - opq;
-                        int32_t left = opq + oplen - q;
-                        for (int b = 0; b < 8; ++b, ++q) {
-                            while (left == 0) {
-                                ++k;
-                                if (k >= ncg) break;
-                                uint32_t v = cg.get(k); op = v & 15u; oplen = (int32_t)(v >> 4);
-                                if (op == OP_H) continue;
-                                if (consumes_query(op)) left = oplen; else if (consumes_ref(op)) rr += oplen;
-                            }
-                            if (k >= ncg) break;
-                            --left;
-                            if (is_match_op(op)) {
-                                const uint32_t qv = ((b & 4 ? qw.y : qw.x) >> ((b & 3) * 8)) & 0xFFu;
-                                if ((int32_t)qv >= mq) {
-                                    const uint32_t byte = (sw >> ((b >> 1) * 8)) & 0xFFu;
-                                    const uint32_t code = (b & 1) ? (byte & 15u) : (byte >> 4);
-                                    const uint32_t col = col_of_code(code);
-                                    if (col > 4u || (uint32_t)rr >= tc.G) bad = true;
-                                    else tile_add(tc, rr, col);
-                                }
-                                ++rr;
-                            }
-                        }
-                    }
+        for (uint32_t base = 0; base < total4; base += T_MAPCAP) {
+            wave_sync();
+            if (counted) {   // read lanes publish chunk -> segment for this round
+                uint32_t cpos = cb4;
+                for (int sgi = 0; sgi < nseg; ++sgi) {
+                    const uint32_t mm = seg[G_M * T_SEGCAP + sb + sgi];
+                    const uint32_t m0 = mm & 0xFFFFu, m1 = mm >> 16;
+                    const uint32_t nc = m1 > m0 ? ((m1 + 7) >> 3) - (m0 >> 3) : 0u;
+                    seg[G_CB * T_SEGCAP + sb + sgi] = cpos;
+                    uint32_t a = cpos > base ? cpos : base, b = cpos + nc < base + T_MAPCAP ? cpos + nc : base + T_MAPCAP;
+                    for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)(sb + sgi);
+                    cpos += nc;
                 }
-                if (bad) __hip_atomic_fetch_or(st + S_INFO * TILE + r, I_ERRFLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_sync();
+            const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
+            for (uint32_t c = lane; c < lim; c += 64) {
+                const uint32_t sg = cmap[c];
+                const uint32_t mm = seg[G_M * T_SEGCAP + sg];
+                const uint32_t r = seg[G_READ * T_SEGCAP + sg];
+                const int32_t m0 = (int32_t)(mm & 0xFFFFu), m1 = (int32_t)(mm >> 16);
+                const uint32_t rcb = seg[G_CB * T_SEGCAP + sg];
+                const int32_t j0 = ((int32_t)(c + base - rcb) + (m0 >> 3)) * 8;
+                const int64_t rb = (int64_t)seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
+                const uint2 qw = *(const uint2 *)(rd.qual + rb);
+                uint32_t sw = *(const uint32_t *)(rd.seq + (rb >> 1));
+                const int32_t d0 = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
+                // per-byte flags (bit 7): base inside [m0, m1) and quality >= min_quality
+                int32_t klo = m0 - j0, khi = m1 - j0;
+                klo = klo < 0 ? 0 : klo; khi = khi > 8 ? 8 : khi;
+                const uint64_t inm = (khi >= 8 ? ~0ull : ((1ull << (khi * 8)) - 1ull)) & ~((1ull << (klo * 8)) - 1ull);
+                uint32_t ok0, ok1;
+                if (mq <= 128) {
+                    const uint32_t mqb = (uint32_t)mq * 0x01010101u;
+                    ok0 = ((((qw.x & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.x) & 0x80808080u;
+                    ok1 = ((((qw.y & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.y) & 0x80808080u;
+                } else {
+                    ok0 = ok1 = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        ok0 |= (((qw.x >> (8 * b)) & 0xFFu) >= (uint32_t)mq ? 0x80u : 0u) << (8 * b);
+                        ok1 |= (((qw.y >> (8 * b)) & 0xFFu) >= (uint32_t)mq ? 0x80u : 0u) << (8 * b);
+                    }
+                }
+                ok0 &= (uint32_t)inm; ok1 &= (uint32_t)(inm >> 32);
+                // any counted base with a code outside A C G T N, or a chunk that leaves the LDS window: careful path
+                sw = ((sw & 0x0F0F0F0Fu) << 4) | ((sw >> 4) & 0x0F0F0F0Fu);   // base k at bits [4k, 4k+4)
+                uint32_t pc = sw - ((sw >> 1) & 0x55555555u);
+                pc = (pc & 0x33333333u) + ((pc >> 2) & 0x33333333u);         // per-nibble popcount
+                const uint32_t odd = (pc ^ 0x11111111u), four = (pc ^ 0x44444444u);
+                // nibble is fine when popcount == 1 or == 4; flag nibbles where neither holds
+                const uint32_t z1 = ((odd | (odd >> 1) | (odd >> 2) | (odd >> 3)) & 0x11111111u);   // 1 where pc != 1
+                const uint32_t z4 = ((four | (four >> 1) | (four >> 2) | (four >> 3)) & 0x11111111u); // 1 where pc != 4
+                const uint32_t nm = (khi >= 8 ? 0xFFFFFFFFu : ((1u << (khi * 4)) - 1u)) & ~((1u << (klo * 4)) - 1u);
+                const bool safe = (z1 & z4 & nm) == 0u && (uint32_t)d0 <= tc.wlim - 8u && tc.wlim >= 8u;
+                if (safe) {
+                    // rotate the 8 bases by `rot` so that lanes serviced together spread over the banks
+                    const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
+                    const uint32_t oa = (rot & 4u) ? ok1 : ok0, ob = (rot & 4u) ? ok0 : ok1;
+                    const uint32_t sh = (rot & 3u) * 8u;
+                    const uint32_t k0 = __builtin_amdgcn_alignbit(ob, oa, sh), k1 = __builtin_amdgcn_alignbit(oa, ob, sh);
+                    const uint32_t sr = __builtin_amdgcn_alignbit(sw, sw, rot * 4u);
+                    lds_u8 *const wbase = (lds_u8 *)win + (uint32_t)d0 * 4u;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const uint32_t val = ((b < 4 ? k0 : k1) >> ((b & 3) * 8 + 7)) & 1u;
+                        const uint32_t code4 = b == 0 ? (sr << 2) & 0x3Cu : (sr >> (4 * b - 2)) & 0x3Cu;
+                        const uint32_t plane = *(lds_u32 *)((lds_u8 *)lut + code4);
+                        const uint32_t bb4 = ((rot + (uint32_t)b) & 7u) * 4u;
+                        lds_add((lds_u32 *)(wbase + plane + bb4), val);
+                    }
+                } else {
+                    bool bad = false;
+#pragma unroll 1
+                    for (int b = 0; b < 8; ++b) {
+                        const uint32_t okb = ((b < 4 ? ok0 : ok1) >> ((b & 3) * 8 + 7)) & 1u;
+                        if (!okb) continue;
+                        const uint32_t col = col_of_code((sw >> (4 * b)) & 15u);
+                        const int32_t rp = win_base + d0 + b;
+                        if (col > 4u || (uint32_t)rp >= tc.G) bad = true;
+                        else tile_add(tc, rp, col);
+                    }
+                    if (bad) st[S_ERR * TILE + r] = 1u;
+                }
+            }
         }
+        wave_sync();
 
         // ---- status / deferral (lane = read) -----------------------------------------------------
         if (valid) {
@@ -572,14 +571,13 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (defer_full) {
                 dlist[atomicAdd(&ctr[3], 1ull)] = (uint32_t)i;
                 status = 0;   // overwritten by the deferred kernel
-            } else if (!status && P.do_count && (cerr || (st[S_INFO * TILE + lane] & I_ERRFLAG))) {
+            } else if (!status && P.do_count && (cerr || st[S_ERR * TILE + lane])) {
                 dlist[atomicAdd(&ctr[3], 1ull)] = (uint32_t)i | DEFER_STATUS_ONLY;
             } else if (status) {
                 ++n_err;
             }
             if (out.status) out.status[i] = (uint8_t)status;
         }
-        wave_sync();
     }
 
     // ---- final flush ------------------------------------------------------------------------
@@ -601,7 +599,7 @@ static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_
                               hipStream_t stream) {
     const int64_t n_tiles = (rd.n_reads + TILE - 1) / TILE;
     if (n_tiles == 0) return 0;
-    int64_t max_blocks = (int64_t)n_cu * 2;
+    int64_t max_blocks = (int64_t)n_cu;
     int64_t tpb = (n_tiles + max_blocks - 1) / max_blocks;
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
     int64_t grid = (n_tiles + tpb - 1) / tpb;
