@@ -40,6 +40,7 @@ constexpr int T_W = 1024;         // reference positions covered by the LDS wind
 constexpr int T_MAXOPS = 8;       // CIGAR ops per read held in LDS (input ops <= T_MAXOPS-3)
 constexpr int T_MAPCAP = T_MAXOPS * TILE * 4;   // chunk-map bytes = the spare CIGAR buffer
 constexpr int T_SEGCAP = 128;     // match-op segments per tile
+constexpr int T_UNROLL = 4;       // chunks per lane whose loads are issued before any of them is processed
 constexpr int32_t NO_WINDOW = INT32_MIN;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -280,6 +281,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int32_t Wd = P.window;
     const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);          // sums of W bytes never reach 256*W
     unsigned long long n_err = 0;
+    const bool stamps = (phases & 0x100u) != 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
         // ---- window management (uniform over the block) ------------------------------------
@@ -307,6 +310,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const int64_t tile = t0 + wave;
         if (tile >= tile_end) continue;
 
+        unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define AMP_STAMP(k) do { if (stamps) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } } while (0)
         // =================================== P1: lane = read ===================================
         const int64_t i = tile * TILE + lane;
         const bool valid = i < n;
@@ -353,6 +358,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         st[S_ERR * TILE + lane] = 0u;
         st[S_CB2 * TILE + lane] = cb2;
 
+        AMP_STAMP(0);
         // =================================== P2: lane = chunk ===================================
         for (uint32_t base = 0; base < total2; base += T_MAPCAP) {
             wave_sync();
@@ -362,31 +368,50 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             wave_sync();
             const uint32_t lim = total2 - base < (uint32_t)T_MAPCAP ? total2 - base : (uint32_t)T_MAPCAP;
-            for (uint32_t c = lane; c < lim; c += 64) {
-                const uint32_t r = cmap[c];
-                const uint32_t lohi = st[S_LOHI * TILE + r];
-                const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
-                const uint32_t rcb = st[S_CB2 * TILE + r];
-                const int32_t j0 = ((int32_t)(c + base - rcb) + (rlo >> 3)) * 8;
-                const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8 + j0;
-                const uint2 w0 = *(const uint2 *)qp;
-                uint2 w1 = make_uint2(0, 0);
-                if (j0 + 8 < rhi) w1 = *(const uint2 *)(qp + 8);
-                const uint32_t w[4] = {w0.x, w0.y, w1.x, w1.y};
-                uint32_t fail = window_fail_bits_dyn(Wd, w, mqc * (uint32_t)Wd);
-                // starts j0+b must lie in [rlo, rhi - W]
-                int32_t blo = rlo - j0, bhi = rhi - Wd - j0;
-                blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
-                fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
-                if (fail) {
-                    uint32_t v;
-                    if (st[S_REV * TILE + r]) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
-                    else v = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);                                 // first failing window start
-                    __hip_atomic_fetch_min(st + S_FF * TILE + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
+                // stage A: owners, addresses and all global loads of T_UNROLL chunks
+                uint32_t rr[T_UNROLL];
+                int32_t jj[T_UNROLL], llo[T_UNROLL], hhi[T_UNROLL];
+                uint2 a0[T_UNROLL], a1[T_UNROLL];
+#pragma unroll
+                for (int u = 0; u < T_UNROLL; ++u) {
+                    const uint32_t c = cc + 64u * u;
+                    a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0);
+                    rr[u] = 0; jj[u] = 0; llo[u] = 0; hhi[u] = 0;
+                    if (c < lim) {
+                        const uint32_t r = cmap[c];
+                        const uint32_t lohi = st[S_LOHI * TILE + r];
+                        const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
+                        const int32_t j0 = ((int32_t)(c + base - st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
+                        const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8 + j0;
+                        a0[u] = *(const uint2 *)qp;
+                        if (j0 + 8 < rhi) a1[u] = *(const uint2 *)(qp + 8);
+                        rr[u] = r; jj[u] = j0; llo[u] = rlo; hhi[u] = rhi;
+                    }
+                }
+                // stage B: window sums and the per-read first / last failing window
+#pragma unroll
+                for (int u = 0; u < T_UNROLL; ++u) {
+                    if (cc + 64u * u < lim) {
+                        const uint32_t w[4] = {a0[u].x, a0[u].y, a1[u].x, a1[u].y};
+                        uint32_t fail = window_fail_bits_dyn(Wd, w, mqc * (uint32_t)Wd);
+                        const int32_t j0 = jj[u], rlo = llo[u], rhi = hhi[u];
+                        int32_t blo = rlo - j0, bhi = rhi - Wd - j0;    // starts j0+b must lie in [rlo, rhi - W]
+                        blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
+                        fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
+                        if (fail) {
+                            const uint32_t r = rr[u];
+                            uint32_t v;
+                            if (st[S_REV * TILE + r]) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
+                            else v = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);                                 // first failing window start
+                            __hip_atomic_fetch_min(st + S_FF * TILE + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
                 }
             }
         }
         wave_sync();
+        AMP_STAMP(1);
 
         // =================================== P3: lane = read ===================================
         int cerr = 0;
@@ -476,6 +501,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         uint32_t total4;
         const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
 
+        AMP_STAMP(2);
         // =================================== P4: lane = chunk ===================================
         for (uint32_t base = 0; base < total4; base += T_MAPCAP) {
             wave_sync();
@@ -493,17 +519,35 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             wave_sync();
             const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
-            for (uint32_t c = lane; c < lim; c += 64) {
-                const uint32_t sg = cmap[c];
-                const uint32_t mm = seg[G_M * T_SEGCAP + sg];
-                const uint32_t r = seg[G_READ * T_SEGCAP + sg];
-                const int32_t m0 = (int32_t)(mm & 0xFFFFu), m1 = (int32_t)(mm >> 16);
-                const uint32_t rcb = seg[G_CB * T_SEGCAP + sg];
-                const int32_t j0 = ((int32_t)(c + base - rcb) + (m0 >> 3)) * 8;
-                const int64_t rb = (int64_t)seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
-                const uint2 qw = *(const uint2 *)(rd.qual + rb);
-                uint32_t sw = *(const uint32_t *)(rd.seq + (rb >> 1));
-                const int32_t d0 = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
+            for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
+              // stage A: owners, addresses and all global loads of T_UNROLL chunks
+              uint2 aq[T_UNROLL];
+              uint32_t as_[T_UNROLL], ar[T_UNROLL];
+              int32_t aj[T_UNROLL], am0[T_UNROLL], am1[T_UNROLL], ad0[T_UNROLL];
+#pragma unroll
+              for (int u = 0; u < T_UNROLL; ++u) {
+                  const uint32_t c = cc + 64u * u;
+                  aq[u] = make_uint2(0, 0); as_[u] = 0; ar[u] = 0; aj[u] = 0; am0[u] = 0; am1[u] = 0; ad0[u] = 0;
+                  if (c < lim) {
+                      const uint32_t sg = cmap[c];
+                      const uint32_t mm = seg[G_M * T_SEGCAP + sg];
+                      const int32_t m0 = (int32_t)(mm & 0xFFFFu);
+                      const int32_t j0 = ((int32_t)(c + base - seg[G_CB * T_SEGCAP + sg]) + (m0 >> 3)) * 8;
+                      const int64_t rb = (int64_t)seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
+                      aq[u] = *(const uint2 *)(rd.qual + rb);
+                      as_[u] = *(const uint32_t *)(rd.seq + (rb >> 1));
+                      ar[u] = seg[G_READ * T_SEGCAP + sg];
+                      aj[u] = j0; am0[u] = m0; am1[u] = (int32_t)(mm >> 16);
+                      ad0[u] = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
+                  }
+              }
+#pragma unroll
+              for (int u = 0; u < T_UNROLL; ++u) {
+                if (cc + 64u * u >= lim) continue;
+                const uint2 qw = aq[u];
+                uint32_t sw = as_[u];
+                const uint32_t r = ar[u];
+                const int32_t j0 = aj[u], m0 = am0[u], m1 = am1[u], d0 = ad0[u];
                 // per-byte flags (bit 7): base inside [m0, m1) and quality >= min_quality
                 int32_t klo = m0 - j0, khi = m1 - j0;
                 klo = klo < 0 ? 0 : klo; khi = khi > 8 ? 8 : khi;
@@ -561,9 +605,11 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                     }
                     if (bad) st[S_ERR * TILE + r] = 1u;
                 }
+              }
             }
         }
         wave_sync();
+        AMP_STAMP(3);
 
         // ---- status / deferral (lane = read) -----------------------------------------------------
         if (valid) {
@@ -578,6 +624,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             if (out.status) out.status[i] = (uint8_t)status;
         }
+        AMP_STAMP(4);
+        tacc[5] += 1;
     }
 
     // ---- final flush ------------------------------------------------------------------------
@@ -592,6 +640,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
+    if (stamps && lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);
 }
 
 static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,

@@ -364,10 +364,10 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     c->d_ins_at = c->d_counts + (size_t)ref_len * AMP_NSYM;
     if (hipMalloc((void **)&c->d_min_start, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_max_end, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
-    if (hipMalloc((void **)&c->d_ctr, 8 * sizeof(unsigned long long)) != hipSuccess) return fail(AMP_ENOMEM);
+    if (hipMalloc((void **)&c->d_ctr, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_ref, (size_t)ref_len) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMemsetAsync(c->d_counts, 0, cb, c->stream) != hipSuccess) return fail(AMP_EHIP);
-    if (hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
+    if (hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
@@ -625,6 +625,14 @@ int amp_get_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap) 
     return AMP_OK;
 }
 
+int amp_debug_counters(amp_ctx *c, uint64_t *out16) {  // raw device counters (development aid)
+    if (!c || !out16) return AMP_EINVAL;
+    Guard g(c);
+    HIPCHK(c, hipMemcpyAsync(out16, c->d_ctr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMP_OK;
+}
+
 int amp_error_reads(amp_ctx *c, int64_t *n) {  // reads with a non-zero status since the last reset
     if (!c || !n) return AMP_EINVAL;
     Guard g(c);
@@ -639,7 +647,7 @@ int amp_reset(amp_ctx *c) {
     if (!c) return AMP_EINVAL;
     Guard g(c);
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_DEV_COLS * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream));
     return AMP_OK;
 }
 

@@ -195,6 +195,9 @@ int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);
 int amp_reset(amp_ctx *ctx); /* zero the count table and drop recorded events */
 /* Number of reads with a non-zero amp_read_status since the last amp_reset. */
 int amp_error_reads(amp_ctx *ctx, int64_t *n);
+/* Development aid: the 16 raw device counters ([0] events, [1] event bound, [2] error reads,
+ * [3] deferred reads, [8..13] per-phase cycle sums when AMPLIHIP_PHASES has bit 0x100). */
+int amp_debug_counters(amp_ctx *ctx, uint64_t *out16);
 /* Pre-size the insertion-event buffer.  Without it every amp_process_batch* call first runs
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
  * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short. */

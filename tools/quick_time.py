@@ -15,3 +15,8 @@ for it in range(4):
     e.reset(); t = time.time(); e.process(b, want_trim=False); dt = time.time() - t
     tot, scan = e.last_kernel_ms()
     print("iter %d: wall %.2f ms, kernels %.3f ms, scan %.3f ms -> %.2f Mreads/s (kernel)" % (it, dt * 1e3, tot, scan, b.n / tot / 1e3))
+dc = e.debug_counters()
+if dc[13]:
+    names = ["P1", "P2", "P3", "P4", "tail"]
+    tot_c = float(sum(dc[8:13]))
+    print("stamps: tiles=%d deferred=%d " % (dc[13], dc[3]) + " ".join("%s=%.0f cyc/tile (%.0f%%)" % (n_, dc[8 + k] / dc[13], 100.0 * dc[8 + k] / tot_c) for k, n_ in enumerate(names)))
