@@ -50,8 +50,8 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;
 
 // per-read state words kept in LDS for the chunk lanes
-enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_WORDS };
-enum : int { G_OFF8, G_M, G_R0, G_READ, G_CB, G_WORDS };   // per-segment words
+enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_T0, S_T1, S_WORDS };   // S_T0/1: 8 quality bytes for the partial windows
+enum : int { G_OFF8, G_M, G_R0, G_RC, G_WORDS };   // per-segment words; G_RC = owner lane | chunk base << 8
 
 struct WaveLds {
     uint32_t cigA[T_MAXOPS * TILE];
@@ -107,9 +107,9 @@ struct TileSink {
 // The skip-ahead variant of the exact walk for REGULAR reads: M/=/X runs and the end clips
 // are stepped over in O(1) (their bases are counted by the chunk lanes / have no effect);
 // deletions, reference skips and insertion runs take exactly the path of count_read_walk.
-template <class CB, class Sink>
+template <class CB, class Sink, class QF>
 __device__ int count_regular_skip(const KParams &P, const CB &cig, int n, int32_t ref_start, int32_t lseq,
-                                  int32_t qs, int32_t qe, const uint8_t *qual, Sink &sink) {
+                                  int32_t qs, int32_t qe, const QF &qual, Sink &sink) {
     const int32_t ref_end = ref_start + reference_length(cig, n);
     const uint32_t G = (uint32_t)P.ref_len;
     const int32_t mq = P.min_quality;
@@ -143,13 +143,13 @@ __device__ int count_regular_skip(const KParams &P, const CB &cig, int n, int32_
             if (is_match_op(it.op) && it.j < it.len) { int32_t rest = it.len - it.j; it.q += rest; it.r += rest; it.j = it.len; }
             continue;
         }
-        if ((int32_t)qual[q] < mq) continue;
+        if ((int32_t)qual(q) < mq) continue;
         if (q < qs) continue;
         if (q >= qe) break;
         const int32_t q0 = q;
         bool q_none = false;
         while (r < 0 && !q_none && q < qe) {
-            if ((int32_t)qual[q] < mq) break;
+            if ((int32_t)qual(q) < mq) break;
             if (!it.next(q, r)) return AMP_RS_INDEX_PAIRS;
             if (q < 0) q_none = true;
         }
@@ -221,6 +221,39 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return incl - v;
 }
 
+// Quality bytes around the first insertion op of a read, fetched early (P1) so that the
+// insertion scan of P3 does not wait on memory; anything else falls back to a global load.
+struct QualCache {
+    const uint8_t *g;
+    int32_t b0;
+    uint32_t w0[4];
+    __device__ __forceinline__ static uint32_t byte_of(const uint32_t (&w)[4], uint32_t k) {
+        const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        return (uint32_t)((k < 8u ? lo : hi) >> ((k & 7u) * 8u)) & 0xFFu;
+    }
+    __device__ __forceinline__ uint32_t operator()(int32_t q) const {
+        const uint32_t k = (uint32_t)(q - b0);
+        if (k < 16u) return byte_of(w0, k);
+        return g[q];
+    }
+};
+
+// Sink of the skip-walk: counts go to the window; the first two insertion events of a read are
+// staged in registers so that the wave can reserve event slots with one atomic.
+struct StageSink {
+    const TileCtx &t;
+    uint32_t read;
+    int n = 0;
+    int32_t p0 = 0, lo0 = 0, hi0 = 0, p1 = 0, lo1 = 0, hi1 = 0;
+    __device__ void add(int32_t r, uint32_t col) { tile_add(t, r, col); }
+    __device__ void event(int32_t pos, int32_t l, int32_t h) {
+        if (n == 0) { p0 = pos; lo0 = l; hi0 = h; }
+        else if (n == 1) { p1 = pos; lo1 = l; hi1 = h; }
+        else t.eb.record(pos, read, l, h);
+        ++n;
+    }
+};
+
 // Classification of a final CIGAR.  regular: H* S* (M|=|X|I|D|N)* S* H* with query length ==
 // lseq.  nseg = number of match ops; plain = regular with no I/D/N at all.
 template <class CB>
@@ -254,6 +287,7 @@ __device__ void classify(const CB &c, int n, int32_t lseq, bool &regular, bool &
 }
 
 // ---------------------------------------------------------------------------------------
+template <bool STAMPS>
 __global__ void __launch_bounds__(T_WAVES * 64)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
        int tiles_per_block, uint32_t phases) {
@@ -281,7 +315,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int32_t Wd = P.window;
     const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);          // sums of W bytes never reach 256*W
     unsigned long long n_err = 0;
-    const bool stamps = (phases & 0x100u) != 0;
+    constexpr bool stamps = STAMPS;
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
@@ -333,8 +367,25 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
         bool can_q = false;
+        QualCache qc;
+        qc.g = qual; qc.b0 = INT32_MIN / 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qc.w0[k] = 0;
         if (mine) {
-            for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
+            int32_t qq = 0, nI = 0;
+            for (int k = 0; k < ncig; ++k) {
+                const uint32_t v = rd.cig[c0 + k], op = v & 15u;
+                cur.set(k, v);
+                if (op == OP_I && nI < 1 && have_qual && P.do_count) {
+                    const int32_t ab = qq & ~7;
+                    const uint2 x = *(const uint2 *)(qual + ab);
+                    uint2 y = make_uint2(0, 0);
+                    if (ab + 8 < lseq) y = *(const uint2 *)(qual + ab + 8);
+                    qc.b0 = ab; qc.w0[0] = x.x; qc.w0[1] = x.y; qc.w0[2] = y.x; qc.w0[3] = y.y;
+                    ++nI;
+                }
+                if (op < 9 && consumes_query(op)) qq += (int32_t)(v >> 4);
+            }
             if (P.do_trim) {
                 trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
                 if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);
@@ -369,15 +420,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             wave_sync();
             const uint32_t lim = total2 - base < (uint32_t)T_MAPCAP ? total2 - base : (uint32_t)T_MAPCAP;
             for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
-                // stage A: owners, addresses and all global loads of T_UNROLL chunks
-                uint32_t rr[T_UNROLL];
-                int32_t jj[T_UNROLL], llo[T_UNROLL], hhi[T_UNROLL];
+                // stage A: all global loads of T_UNROLL chunks (only the data stays live)
                 uint2 a0[T_UNROLL], a1[T_UNROLL];
 #pragma unroll
                 for (int u = 0; u < T_UNROLL; ++u) {
                     const uint32_t c = cc + 64u * u;
                     a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0);
-                    rr[u] = 0; jj[u] = 0; llo[u] = 0; hhi[u] = 0;
                     if (c < lim) {
                         const uint32_t r = cmap[c];
                         const uint32_t lohi = st[S_LOHI * TILE + r];
@@ -386,27 +434,42 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                         const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8 + j0;
                         a0[u] = *(const uint2 *)qp;
                         if (j0 + 8 < rhi) a1[u] = *(const uint2 *)(qp + 8);
-                        rr[u] = r; jj[u] = j0; llo[u] = rlo; hhi[u] = rhi;
                     }
                 }
                 // stage B: window sums and the per-read first / last failing window
 #pragma unroll
                 for (int u = 0; u < T_UNROLL; ++u) {
-                    if (cc + 64u * u < lim) {
+                    const uint32_t c = cc + 64u * u;
+                    if (c < lim) {
+                        const uint32_t r = cmap[c];
+                        const uint32_t lohi = st[S_LOHI * TILE + r];
+                        const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
+                        const int32_t j0 = ((int32_t)(c + base - st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
                         const uint32_t w[4] = {a0[u].x, a0[u].y, a1[u].x, a1[u].y};
                         uint32_t fail = window_fail_bits_dyn(Wd, w, mqc * (uint32_t)Wd);
-                        const int32_t j0 = jj[u], rlo = llo[u], rhi = hhi[u];
+                        const bool rv = st[S_REV * TILE + r] != 0;
+                        {   // the chunk next to the 3' end keeps the bytes of the shrinking windows for P3
+                            const int32_t o = rv ? rlo - j0 : rhi - Wd + 1 - j0;     // first byte wanted
+                            if (rv ? (j0 <= rlo) : (rhi - Wd < j0 + 8)) {
+                                const uint64_t lo64 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi64 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+                                const uint32_t sh = ((uint32_t)o & 7u) * 8u;
+                                uint64_t tb = (uint32_t)o >= 8u ? hi64 : lo64;
+                                if (sh) tb = (lo64 >> sh) | (hi64 << (64u - sh));
+                                st[S_T0 * TILE + r] = (uint32_t)tb;
+                                st[S_T1 * TILE + r] = (uint32_t)(tb >> 32);
+                            }
+                        }
                         int32_t blo = rlo - j0, bhi = rhi - Wd - j0;    // starts j0+b must lie in [rlo, rhi - W]
                         blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
                         fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
                         if (fail) {
-                            const uint32_t r = rr[u];
                             uint32_t v;
-                            if (st[S_REV * TILE + r]) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
+                            if (rv) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
                             else v = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);                                 // first failing window start
                             __hip_atomic_fetch_min(st + S_FF * TILE + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // one chunk at a time: keeps the live set small
                 }
             }
         }
@@ -425,12 +488,21 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                     iq = rev ? (int32_t)(0xFFFFu - v) : (int32_t)v;
                 } else {
                     // no full window failed: the shrinking windows at the 3' end decide (A:575-576, A:637-638)
-                    const uint8_t *q = qual + lo;
                     iq = rev ? 0 : qlen;
                     int32_t acc = 0;
-                    for (int32_t k = 1; k < Wd && k <= qlen; ++k) {
-                        acc += rev ? q[k - 1] : q[qlen - k];
-                        if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
+                    if (qlen >= Wd) {
+                        // stash = 8 bytes starting at lo (reverse) / at hi - W + 1 (forward)
+                        const uint64_t tb = (uint64_t)st[S_T0 * TILE + lane] | ((uint64_t)st[S_T1 * TILE + lane] << 32);
+                        for (int32_t k = 1; k < Wd; ++k) {
+                            acc += (int32_t)((tb >> ((rev ? k - 1 : Wd - 1 - k) * 8)) & 0xFFu);
+                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
+                        }
+                    } else {
+                        const uint8_t *q = qual + lo;
+                        for (int32_t k = 1; k <= qlen; ++k) {
+                            acc += rev ? q[k - 1] : q[qlen - k];
+                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
+                        }
                     }
                 }
             } else {
@@ -462,13 +534,13 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (!have_qual) regular = false;
             int e1 = 0, e2 = 0;
             if (regular) { fqs = query_alignment_start(cur, ts.n, lseq, e1); fqe = query_alignment_end(cur, ts.n, lseq, e2); }
-            if (!regular || e1 || e2) { defer_full = true; nseg = 0; }
+            if (!regular || e1 || e2) { defer_full = true; nseg = 0; if (stamps) atomicAdd(&ctr[6], 1ull); }
             else counted = true;
         }
         // segments: one per match op, allotted by a wave scan; a read that does not fit is deferred
         uint32_t total_seg;
         uint32_t sb = wave_excl_scan((uint32_t)nseg, lane, total_seg);
-        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }
+        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; if (stamps) atomicAdd(&ctr[7], 1ull); }
         uint32_t nch4 = 0;
         if (counted) {
             int32_t q = 0, r = ts.pos;
@@ -481,20 +553,38 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                         seg[G_OFF8 * T_SEGCAP + sidx] = off8;
                         seg[G_M * T_SEGCAP + sidx] = (uint32_t)q | ((uint32_t)(q + len) << 16);
                         seg[G_R0 * T_SEGCAP + sidx] = (uint32_t)r;
-                        seg[G_READ * T_SEGCAP + sidx] = (uint32_t)lane;
+                        seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
                         nch4 += (uint32_t)(((q + len + 7) >> 3) - (q >> 3));
                     } else {
                         seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_OFF8 * T_SEGCAP + sidx] = off8; seg[G_R0 * T_SEGCAP + sidx] = 0u;
-                        seg[G_READ * T_SEGCAP + sidx] = (uint32_t)lane;
+                        seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
                     }
                     ++sidx;
                     q += len; r += len;
                 } else if (op == OP_I || op == OP_S) q += len;
                 else if (op == OP_D || op == OP_N) r += len;
             }
-            if (!plain && (phases & 8u)) {
-                TileSink sink{tc, (uint32_t)(read_base + (uint64_t)i)};
-                cerr = count_regular_skip(P, cur, ts.n, ts.pos, lseq, fqs, fqe, qual, sink);
+        }
+        StageSink ssink{tc, (uint32_t)(read_base + (uint64_t)i)};
+        if (counted && !plain && (phases & 8u)) cerr = count_regular_skip(P, cur, ts.n, ts.pos, lseq, fqs, fqe, qc, ssink);
+        {   // one reservation of event slots per wave
+            const uint32_t ne = (uint32_t)(ssink.n < 2 ? ssink.n : 2);
+            uint32_t tot_e;
+            const uint32_t eo = wave_excl_scan(ne, lane, tot_e);
+            if (tot_e) {
+                unsigned long long ebase = 0;
+                if (lane == 0) ebase = atomicAdd(&ctr[0], (unsigned long long)tot_e);
+                ebase = __shfl(ebase, 0);
+                if (ne >= 1) {
+                    const unsigned long long idx = ebase + eo;
+                    if ((long long)idx < eb.cap) eb.ev[idx] = amp_ins_event{ssink.p0, ssink.read, ssink.lo0, ssink.hi0};
+                    atomicAdd(&eb.ins_at[ssink.p0], 1u);
+                }
+                if (ne >= 2) {
+                    const unsigned long long idx = ebase + eo + 1;
+                    if ((long long)idx < eb.cap) eb.ev[idx] = amp_ins_event{ssink.p1, ssink.read, ssink.lo1, ssink.hi1};
+                    atomicAdd(&eb.ins_at[ssink.p1], 1u);
+                }
             }
         }
         if (!(phases & 4u)) nch4 = 0;
@@ -511,7 +601,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                     const uint32_t mm = seg[G_M * T_SEGCAP + sb + sgi];
                     const uint32_t m0 = mm & 0xFFFFu, m1 = mm >> 16;
                     const uint32_t nc = m1 > m0 ? ((m1 + 7) >> 3) - (m0 >> 3) : 0u;
-                    seg[G_CB * T_SEGCAP + sb + sgi] = cpos;
+                    seg[G_RC * T_SEGCAP + sb + sgi] = (uint32_t)lane | (cpos << 8);
                     uint32_t a = cpos > base ? cpos : base, b = cpos + nc < base + T_MAPCAP ? cpos + nc : base + T_MAPCAP;
                     for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)(sb + sgi);
                     cpos += nc;
@@ -520,34 +610,33 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             wave_sync();
             const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
             for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
-              // stage A: owners, addresses and all global loads of T_UNROLL chunks
+              // stage A: all global loads of T_UNROLL chunks (only the data stays live)
               uint2 aq[T_UNROLL];
-              uint32_t as_[T_UNROLL], ar[T_UNROLL];
-              int32_t aj[T_UNROLL], am0[T_UNROLL], am1[T_UNROLL], ad0[T_UNROLL];
+              uint32_t as_[T_UNROLL];
 #pragma unroll
               for (int u = 0; u < T_UNROLL; ++u) {
                   const uint32_t c = cc + 64u * u;
-                  aq[u] = make_uint2(0, 0); as_[u] = 0; ar[u] = 0; aj[u] = 0; am0[u] = 0; am1[u] = 0; ad0[u] = 0;
+                  aq[u] = make_uint2(0, 0); as_[u] = 0;
                   if (c < lim) {
                       const uint32_t sg = cmap[c];
-                      const uint32_t mm = seg[G_M * T_SEGCAP + sg];
-                      const int32_t m0 = (int32_t)(mm & 0xFFFFu);
-                      const int32_t j0 = ((int32_t)(c + base - seg[G_CB * T_SEGCAP + sg]) + (m0 >> 3)) * 8;
+                      const int32_t m0 = (int32_t)(seg[G_M * T_SEGCAP + sg] & 0xFFFFu);
+                      const int32_t j0 = ((int32_t)(c + base - (seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
                       const int64_t rb = (int64_t)seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
                       aq[u] = *(const uint2 *)(rd.qual + rb);
                       as_[u] = *(const uint32_t *)(rd.seq + (rb >> 1));
-                      ar[u] = seg[G_READ * T_SEGCAP + sg];
-                      aj[u] = j0; am0[u] = m0; am1[u] = (int32_t)(mm >> 16);
-                      ad0[u] = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
                   }
               }
 #pragma unroll
               for (int u = 0; u < T_UNROLL; ++u) {
-                if (cc + 64u * u >= lim) continue;
+                const uint32_t c = cc + 64u * u;
+                if (c >= lim) continue;
+                const uint32_t sg = cmap[c];
+                const uint32_t mm = seg[G_M * T_SEGCAP + sg];
+                const int32_t m0 = (int32_t)(mm & 0xFFFFu), m1 = (int32_t)(mm >> 16);
+                const int32_t j0 = ((int32_t)(c + base - (seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
+                const int32_t d0 = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
                 const uint2 qw = aq[u];
                 uint32_t sw = as_[u];
-                const uint32_t r = ar[u];
-                const int32_t j0 = aj[u], m0 = am0[u], m1 = am1[u], d0 = ad0[u];
                 // per-byte flags (bit 7): base inside [m0, m1) and quality >= min_quality
                 int32_t klo = m0 - j0, khi = m1 - j0;
                 klo = klo < 0 ? 0 : klo; khi = khi > 8 ? 8 : khi;
@@ -603,8 +692,9 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                         if (col > 4u || (uint32_t)rp >= tc.G) bad = true;
                         else tile_add(tc, rp, col);
                     }
-                    if (bad) st[S_ERR * TILE + r] = 1u;
+                    if (bad) st[S_ERR * TILE + (seg[G_RC * T_SEGCAP + sg] & 0xFFu)] = 1u;
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one chunk at a time: keeps the live set small
               }
             }
         }
@@ -619,6 +709,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 status = 0;   // overwritten by the deferred kernel
             } else if (!status && P.do_count && (cerr || st[S_ERR * TILE + lane])) {
                 dlist[atomicAdd(&ctr[3], 1ull)] = (uint32_t)i | DEFER_STATUS_ONLY;
+                if (stamps) atomicAdd(&ctr[cerr ? 14 : 15], 1ull);
             } else if (status) {
                 ++n_err;
             }
@@ -652,7 +743,8 @@ static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_
     int64_t tpb = (n_tiles + max_blocks - 1) / max_blocks;
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
     int64_t grid = (n_tiles + tpb - 1) / tpb;
-    k_tile<<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
+    if (phases & 0x100u) k_tile<true><<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
+    else k_tile<false><<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
     return (int)hipGetLastError();
 }
 

@@ -74,7 +74,7 @@ struct amp_ctx {
     bool timed = false;
     int n_cu = 256;
     int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = tile kernel
-    uint32_t phases = 0xFFFFFFFFu; // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
+    uint32_t phases = 0xFFu;       // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
     char err[320] = {0};
 };
 

@@ -19,4 +19,5 @@ dc = e.debug_counters()
 if dc[13]:
     names = ["P1", "P2", "P3", "P4", "tail"]
     tot_c = float(sum(dc[8:13]))
+    print("defer reasons: irregular=%d segcap=%d cerr=%d chunk_err=%d" % (dc[6], dc[7], dc[14], dc[15]))
     print("stamps: tiles=%d deferred=%d " % (dc[13], dc[3]) + " ".join("%s=%.0f cyc/tile (%.0f%%)" % (n_, dc[8 + k] / dc[13], 100.0 * dc[8 + k] / tot_c) for k, n_ in enumerate(names)))
