@@ -47,7 +47,9 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 // entries of the deferred list: read index | kind
-constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;
+constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;   // counted by the tile kernel; only the exact status is missing
+constexpr uint32_t DEFER_INDELS = 0x40000000u;        // match bases counted by the tile kernel; deletions / insertion events missing
+constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 
 // per-read state words kept in LDS for the chunk lanes
 enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_T0, S_T1, S_WORDS };   // S_T0/1: 8 quality bytes for the partial windows
@@ -221,39 +223,6 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return incl - v;
 }
 
-// Quality bytes around the first insertion op of a read, fetched early (P1) so that the
-// insertion scan of P3 does not wait on memory; anything else falls back to a global load.
-struct QualCache {
-    const uint8_t *g;
-    int32_t b0;
-    uint32_t w0[4];
-    __device__ __forceinline__ static uint32_t byte_of(const uint32_t (&w)[4], uint32_t k) {
-        const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-        return (uint32_t)((k < 8u ? lo : hi) >> ((k & 7u) * 8u)) & 0xFFu;
-    }
-    __device__ __forceinline__ uint32_t operator()(int32_t q) const {
-        const uint32_t k = (uint32_t)(q - b0);
-        if (k < 16u) return byte_of(w0, k);
-        return g[q];
-    }
-};
-
-// Sink of the skip-walk: counts go to the window; the first two insertion events of a read are
-// staged in registers so that the wave can reserve event slots with one atomic.
-struct StageSink {
-    const TileCtx &t;
-    uint32_t read;
-    int n = 0;
-    int32_t p0 = 0, lo0 = 0, hi0 = 0, p1 = 0, lo1 = 0, hi1 = 0;
-    __device__ void add(int32_t r, uint32_t col) { tile_add(t, r, col); }
-    __device__ void event(int32_t pos, int32_t l, int32_t h) {
-        if (n == 0) { p0 = pos; lo0 = l; hi0 = h; }
-        else if (n == 1) { p1 = pos; lo1 = l; hi1 = h; }
-        else t.eb.record(pos, read, l, h);
-        ++n;
-    }
-};
-
 // Classification of a final CIGAR.  regular: H* S* (M|=|X|I|D|N)* S* H* with query length ==
 // lseq.  nseg = number of match ops; plain = regular with no I/D/N at all.
 template <class CB>
@@ -367,25 +336,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
         bool can_q = false;
-        QualCache qc;
-        qc.g = qual; qc.b0 = INT32_MIN / 2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) qc.w0[k] = 0;
         if (mine) {
-            int32_t qq = 0, nI = 0;
-            for (int k = 0; k < ncig; ++k) {
-                const uint32_t v = rd.cig[c0 + k], op = v & 15u;
-                cur.set(k, v);
-                if (op == OP_I && nI < 1 && have_qual && P.do_count) {
-                    const int32_t ab = qq & ~7;
-                    const uint2 x = *(const uint2 *)(qual + ab);
-                    uint2 y = make_uint2(0, 0);
-                    if (ab + 8 < lseq) y = *(const uint2 *)(qual + ab + 8);
-                    qc.b0 = ab; qc.w0[0] = x.x; qc.w0[1] = x.y; qc.w0[2] = y.x; qc.w0[3] = y.y;
-                    ++nI;
-                }
-                if (op < 9 && consumes_query(op)) qq += (int32_t)(v >> 4);
-            }
+            for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
             if (P.do_trim) {
                 trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
                 if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);
@@ -477,7 +429,6 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         AMP_STAMP(1);
 
         // =================================== P3: lane = read ===================================
-        int cerr = 0;
         int nseg = 0;
         bool counted = false;
         if (mine && !ts.err && P.do_trim && can_q) {
@@ -527,13 +478,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (out.trim_flags) out.trim_flags[i] = ts.err ? (uint8_t)0 : (uint8_t)ts.flags;
         }
         bool plain = false;
-        int32_t fqs = 0, fqe = 0;
         if (mine && !ts.err && P.do_count) {
             bool regular;
             classify(cur, ts.n, lseq, regular, plain, nseg);
             if (!have_qual) regular = false;
             int e1 = 0, e2 = 0;
-            if (regular) { fqs = query_alignment_start(cur, ts.n, lseq, e1); fqe = query_alignment_end(cur, ts.n, lseq, e2); }
+            if (regular) { (void)query_alignment_start(cur, ts.n, lseq, e1); (void)query_alignment_end(cur, ts.n, lseq, e2); }
             if (!regular || e1 || e2) { defer_full = true; nseg = 0; if (stamps) atomicAdd(&ctr[6], 1ull); }
             else counted = true;
         }
@@ -565,28 +515,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 else if (op == OP_D || op == OP_N) r += len;
             }
         }
-        StageSink ssink{tc, (uint32_t)(read_base + (uint64_t)i)};
-        if (counted && !plain && (phases & 8u)) cerr = count_regular_skip(P, cur, ts.n, ts.pos, lseq, fqs, fqe, qc, ssink);
-        {   // one reservation of event slots per wave
-            const uint32_t ne = (uint32_t)(ssink.n < 2 ? ssink.n : 2);
-            uint32_t tot_e;
-            const uint32_t eo = wave_excl_scan(ne, lane, tot_e);
-            if (tot_e) {
-                unsigned long long ebase = 0;
-                if (lane == 0) ebase = atomicAdd(&ctr[0], (unsigned long long)tot_e);
-                ebase = __shfl(ebase, 0);
-                if (ne >= 1) {
-                    const unsigned long long idx = ebase + eo;
-                    if ((long long)idx < eb.cap) eb.ev[idx] = amp_ins_event{ssink.p0, ssink.read, ssink.lo0, ssink.hi0};
-                    atomicAdd(&eb.ins_at[ssink.p0], 1u);
-                }
-                if (ne >= 2) {
-                    const unsigned long long idx = ebase + eo + 1;
-                    if ((long long)idx < eb.cap) eb.ev[idx] = amp_ins_event{ssink.p1, ssink.read, ssink.lo1, ssink.hi1};
-                    atomicAdd(&eb.ins_at[ssink.p1], 1u);
-                }
-            }
-        }
+        const bool defer_indels = counted && !plain;   // deletions and insertion events: compacted second pass
         if (!(phases & 4u)) nch4 = 0;
         uint32_t total4;
         const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
@@ -673,13 +602,17 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                     const uint32_t k0 = __builtin_amdgcn_alignbit(ob, oa, sh), k1 = __builtin_amdgcn_alignbit(oa, ob, sh);
                     const uint32_t sr = __builtin_amdgcn_alignbit(sw, sw, rot * 4u);
                     lds_u8 *const wbase = (lds_u8 *)win + (uint32_t)d0 * 4u;
+                    uint32_t plane[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {    // all eight table reads first: they cannot move past the atomics
+                        const uint32_t code4 = b == 0 ? (sr << 2) & 0x3Cu : (sr >> (4 * b - 2)) & 0x3Cu;
+                        plane[b] = *(lds_u32 *)((lds_u8 *)lut + code4);
+                    }
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         const uint32_t val = ((b < 4 ? k0 : k1) >> ((b & 3) * 8 + 7)) & 1u;
-                        const uint32_t code4 = b == 0 ? (sr << 2) & 0x3Cu : (sr >> (4 * b - 2)) & 0x3Cu;
-                        const uint32_t plane = *(lds_u32 *)((lds_u8 *)lut + code4);
                         const uint32_t bb4 = ((rot + (uint32_t)b) & 7u) * 4u;
-                        lds_add((lds_u32 *)(wbase + plane + bb4), val);
+                        lds_add((lds_u32 *)(wbase + plane[b] + bb4), val);
                     }
                 } else {
                     bool bad = false;
@@ -701,19 +634,27 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         wave_sync();
         AMP_STAMP(3);
 
-        // ---- status / deferral (lane = read) -----------------------------------------------------
-        if (valid) {
+        // ---- status / deferral (lane = read): one list reservation per wave -------------------------
+        {
             uint32_t status = (uint32_t)ts.err;
-            if (defer_full) {
-                dlist[atomicAdd(&ctr[3], 1ull)] = (uint32_t)i;
-                status = 0;   // overwritten by the deferred kernel
-            } else if (!status && P.do_count && (cerr || st[S_ERR * TILE + lane])) {
-                dlist[atomicAdd(&ctr[3], 1ull)] = (uint32_t)i | DEFER_STATUS_ONLY;
-                if (stamps) atomicAdd(&ctr[cerr ? 14 : 15], 1ull);
-            } else if (status) {
-                ++n_err;
+            uint32_t entry = 0;
+            bool has = false;
+            if (valid) {
+                if (defer_full) { entry = (uint32_t)i; has = true; status = 0; }
+                else if (!status && P.do_count) {
+                    if (defer_indels) { entry = (uint32_t)i | DEFER_INDELS; has = true; }
+                    if (st[S_ERR * TILE + lane]) { entry |= (uint32_t)i | DEFER_STATUS_ONLY; has = true; }
+                }
+                if (status) ++n_err;
+                if (out.status) out.status[i] = (uint8_t)status;
             }
-            if (out.status) out.status[i] = (uint8_t)status;
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                unsigned long long dbase = 0;
+                if (lane == 0) dbase = atomicAdd(&ctr[3], (unsigned long long)__popcll(m));
+                dbase = __shfl(dbase, 0);
+                if (has) dlist[dbase + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+            }
         }
         AMP_STAMP(4);
         tacc[5] += 1;

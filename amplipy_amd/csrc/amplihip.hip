@@ -187,7 +187,24 @@ k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32
     process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, false);
 }
 
-// Second pass of variant 2: the reads the tile kernel put on its deferred list.
+// Deletions / reference skips and insertion events of a read whose match bases the tile kernel
+// already counted: the skip-ahead walk over the FINAL CIGAR the tile kernel wrote out.
+__device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
+                                   uint32_t *counts, const EventBuf &eb) {
+    const size_t slot = (size_t)rd.cig_off32[i] + 3 * (size_t)i;
+    const CigBuf<1> cig{out.new_cig + slot};
+    const int n = (int)out.new_ncig[i];
+    const int32_t lseq = (int32_t)rd.lseq[i];
+    const uint8_t *qual = rd.qual + (int64_t)rd.seq_off8[i] * 8;
+    int e1 = 0, e2 = 0;
+    const int32_t qs = query_alignment_start(cig, n, lseq, e1), qe = query_alignment_end(cig, n, lseq, e2);
+    DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
+    struct Q { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } } qf{qual};
+    return count_regular_skip(P, cig, n, out.new_pos[i], lseq, qs, qe, qf, sink);
+}
+
+// Second pass of variant 2: the reads the tile kernel put on its deferred list, one per lane.
+// The list is dense, so the serial per-read code runs with every lane busy.
 __global__ void __launch_bounds__(256)
 k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
                  EventBuf eb, const uint32_t *dlist) {
@@ -195,7 +212,13 @@ k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
     for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
          k += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t e = dlist[k];
-        process_read_serial(P, rd, (int64_t)(e & 0x7FFFFFFFu), read_base, out, scratch, counts, eb, (e & DEFER_STATUS_ONLY) != 0);
+        const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
+        bool status_only = (e & DEFER_STATUS_ONLY) != 0;
+        if (e & DEFER_INDELS) {
+            if (process_read_indels(P, rd, i, read_base, out, counts, eb)) status_only = true;   // exact status below
+            else if (!status_only) continue;
+        }
+        process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, status_only);
     }
 }
 
@@ -488,11 +511,17 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const size_t slots = (size_t)rd->n_cig + 3 * (size_t)n;
     DevOut out{o ? o->new_pos : nullptr, o ? o->new_ncig : nullptr, o ? o->new_cig : nullptr, o ? o->ref_len : nullptr,
                o ? o->trim_flags : nullptr, o ? o->status : nullptr};
-    // scratch: [CIGAR ping-pong slots][deferred list][trimmed CIGARs when the caller does not want them]
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n) * 4));
+    // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
+    if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;
-    if (!out.new_cig) out.new_cig = dlist + n;
+    uint32_t *extra = dlist + n;
+    if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
+    extra += n;
+    if (!out.new_ncig) { out.new_ncig = extra; }
+    extra += n;
+    if (!out.new_cig) out.new_cig = extra;
     const EventBuf eb{c->events.as<amp_ins_event>(), c->d_ctr, c->d_ins_at, (long long)c->ev_cap};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (c->kernel_variant == 1) {
