@@ -1,0 +1,354 @@
+"""Host mirror of AmpliPy's command-line / run_amplipy surface on top of the HIP engine.
+
+Same sub-commands, flags, defaults, log lines and error behaviour as AmpliPy.py v0.0.2
+(parse_args AmpliPy.py:113-171, run_amplipy :774-963, __main__ :966-1025); the per-read loop
+(:896-915) is replaced by batches handed to libamplihip.so, calling (:917-952) by
+``amplipy_amd.calling``, and pysam I/O by ``amplipy_amd.bamio``.  There is no CPU execution
+path: without a GPU the engine raises.
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import sys
+from datetime import datetime
+from os.path import isfile
+
+import numpy as np
+
+from . import AMPLIPY_VERSION, abi, bamio, calling, lib
+from .batch import ReadBatch
+from .insertions import event_strings
+
+VERSION = AMPLIPY_VERSION
+PROGRESS_NUM_READS = 50000          # AmpliPy.py:19
+BATCH_READS = 1 << 18
+
+DEFAULTS = dict(min_depth_consensus=10, min_depth_variants=1, min_freq_consensus=0, min_freq_variants=0.03,
+                min_length=30, min_quality=20, primer_pos_offset=0, sliding_window_width=4, unknown_symbol="N")
+
+
+def print_log(s="", end="\n"):
+    print("[%s] %s" % (datetime.now().strftime("%Y-%m-%d %H:%M:%S"), s), end=end, file=sys.stderr)
+    sys.stderr.flush()
+
+
+def error(s=None):
+    print_log("ERROR" if s is None else "ERROR: %s" % s)
+    sys.exit(1)
+
+
+# ---- loaders (AmpliPy.py:212-258) --------------------------------------------------------------
+def load_ref_genome(reference_fn):
+    if not isfile(reference_fn):
+        error("File not found: %s" % reference_fn)
+    with open(reference_fn) as f:
+        lines = f.read().strip().splitlines()
+    if len(lines) < 2 or not lines[0].startswith(">"):
+        error("Invalid FASTA file: %s" % reference_fn)
+    ref_id = lines[0][1:].split()[0].strip()
+    seq = "".join(lines[1:])
+    if ">" in seq:
+        error("Multiple sequences in FASTA file: %s" % reference_fn)
+    return ref_id, seq
+
+
+def load_primers(primer_fn):
+    if not isfile(primer_fn):
+        error("File not found: %s" % primer_fn)
+    with open(primer_fn) as f:
+        lines = f.read().strip().splitlines()
+    primers = []
+    for l in lines:
+        parts = l.split("\t")
+        try:
+            if len(parts) != 4:
+                raise ValueError
+            primers.append((int(parts[1]), int(parts[2])))
+        except ValueError:
+            error("Invalid primer BED line: %s" % l)
+    if not primers:
+        raise NameError("name 'header' is not defined")      # what the reference does on an empty BED (:255)
+    primers.sort()
+    return primers
+
+
+# ---- output openers (AmpliPy.py:261-360) --------------------------------------------------------
+def _reads_mode(fn, write):
+    low = fn.lower()
+    if low.endswith(".sam"):
+        return "w" if write else "r"
+    if low.endswith(".bam"):
+        return "wb" if write else "rb"
+    error("Invalid read mapping extension (should be .sam or .bam): %s" % fn)
+
+
+def open_alignment_files(input_fn, output_fn):
+    if input_fn is None:
+        error("Input alignment file is None")
+    if input_fn.lower() == "stdin":
+        reader = bamio.AlignmentReader("-", "r")
+    elif not isfile(input_fn):
+        error("File not found: %s" % input_fn)
+    else:
+        reader = bamio.AlignmentReader(input_fn, _reads_mode(input_fn, False))
+    writer = None
+    if output_fn is not None:
+        hdr = reader.header.with_amplipy_pg(VERSION, " ".join(sys.argv))
+        if output_fn.lower() == "stdout":
+            writer = bamio.AlignmentWriter("-", "w", hdr)
+        elif isfile(output_fn):
+            error("File already exists: %s" % output_fn)
+        else:
+            writer = bamio.AlignmentWriter(output_fn, _reads_mode(output_fn, True), hdr)
+    return reader, writer
+
+
+class VcfWriter:
+    """Text VCF with the header AmpliPy builds through pysam (AmpliPy.py:271-281)."""
+
+    def __init__(self, fn, ref_id):
+        if fn.lower() == "stdout":
+            self.f = sys.stdout
+        elif isfile(fn):
+            error("File already exists: %s" % fn)
+        elif fn.lower().endswith(".vcf"):
+            self.f = open(fn, "w")
+        elif fn.lower().endswith(".vcf.gz"):
+            self.f = gzip.open(fn, "wt")
+        elif fn.lower().endswith(".bcf"):
+            error("BCF output is not supported by this build (use .vcf or .vcf.gz): %s" % fn)
+        else:
+            error("Invalid variants extension (should be .vcf, .vcf.gz, or .bcf): %s" % fn)
+        self.ref_id = ref_id
+        w = self.f.write
+        w("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n")
+        w("##AmpliPyVersion=%s\n##source=%s\n##contig=<ID=%s>\n" % (VERSION, " ".join(sys.argv), ref_id))
+        w("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n")
+        w("##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Total Depth\">\n")
+        w("##INFO=<ID=REF_DP,Number=1,Type=Integer,Description=\"Depth of reference base\">\n")
+        w("##INFO=<ID=ALT_DP,Number=1,Type=String,Description=\"Depth of alternate base\">\n")
+        w("##INFO=<ID=REF_FREQ,Number=1,Type=Float,Description=\"Frequency of reference base\">\n")
+        w("##INFO=<ID=ALT_FREQ,Number=1,Type=String,Description=\"Frequency of alternate base\">\n")
+        w("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n")
+
+    def write(self, r):
+        info = "DP=%d;REF_DP=%d;ALT_DP=%s;REF_FREQ=%s;ALT_FREQ=%s" % (r.DP, r.REF_DP, r.ALT_DP, "%g" % r.REF_FREQ, r.ALT_FREQ)
+        self.f.write("%s\t%d\t.\t%s\t%s\t.\tPASS\t%s\tGT\t%s\n" % (self.ref_id, r.pos + 1, r.ref, ",".join(r.alts), info,
+                                                                    "/".join(str(g) for g in r.GT)))
+
+    def close(self):
+        if self.f is not sys.stdout:
+            self.f.close()
+
+
+def _raise_for_status(status):
+    exc = abi.READ_STATUS_EXC[int(status)]
+    raise exc("read rejected by the engine: %s (the reference raises %s here)" % (abi.READ_STATUS_NAMES[int(status)], exc.__name__))
+
+
+def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trimmed_reads_fn=None, variants_fn=None,
+                consensus_fn=None, primer_pos_offset=None, min_length=None, min_quality=None, sliding_window_width=None,
+                min_freq_consensus=None, min_freq_variants=None, min_depth_consensus=None, min_depth_variants=None,
+                unknown_symbol=None, include_no_primer=None, run_trim=False, run_variants=False, run_consensus=False,
+                device=0):
+    # argument checks and banner: AmpliPy.py:836-866
+    if primer_pos_offset is not None and primer_pos_offset < 0:
+        error("Primer position offset must be non-negative: %s" % primer_pos_offset)
+    if min_length is not None and min_length < 1:
+        error("Minimum length must be >= 1: %s" % min_length)
+    if min_quality is not None and min_quality < 0:
+        error("Minimum quality must be non-negative: %s" % min_quality)
+    if sliding_window_width is not None and sliding_window_width < 1:
+        error("Sliding window width must be >= 1: %s" % sliding_window_width)
+    for v in (min_freq_consensus, min_freq_variants):
+        if v is not None and (v < 0 or v > 1):
+            error("Minimum frequency must be between 0 and 1: %s" % v)
+    for v in (min_depth_consensus, min_depth_variants):
+        if v is not None and v < 0:
+            error("Minimum depth must be positive: %s" % v)
+    if unknown_symbol is not None and len(unknown_symbol) != 1:
+        error("Unknown symbol must be exactly 1 character: %s" % unknown_symbol)
+    if not (run_trim or run_variants or run_consensus):
+        error("Not running any of the AmpliPy operations")
+    mode = "Trim" if run_trim and not (run_variants or run_consensus) else \
+        "Variants" if run_variants and not (run_trim or run_consensus) else \
+        "Consensus" if run_consensus and not (run_trim or run_variants) else "All-In-One"
+    print_log("Executing AmpliPy %s (v%s)" % (mode, VERSION))
+
+    ref_id = ref_seq = None
+    if reference_fn is not None:
+        print_log("Loading reference genome: %s" % reference_fn)
+        ref_id, ref_seq = load_ref_genome(reference_fn)
+    G = len(ref_seq)
+    eng = lib.Engine(G, device=device)
+    if primer_fn is not None:
+        print_log("Loading primers: %s" % primer_fn)
+        primers = load_primers(primer_fn)
+        print_log("Precalculating overlapping primers...")
+        mn, mx, mpl = lib.find_overlapping_primers(G, primers, primer_pos_offset)
+        eng.set_primers(mn, mx, mpl)
+    if run_trim:
+        print_log("Input untrimmed SAM/BAM: %s" % untrimmed_reads_fn)
+        print_log("Output trimmed SAM/BAM: %s" % trimmed_reads_fn)
+        reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
+    else:
+        print_log("Input trimmed SAM/BAM: %s" % trimmed_reads_fn)
+        reader, writer = open_alignment_files(trimmed_reads_fn, None)
+    vcf = None
+    if variants_fn is not None:
+        print_log("Output variants VCF: %s" % variants_fn)
+        vcf = VcfWriter(variants_fn, ref_id)
+    do_count = run_variants or run_consensus
+    eng.set_params(min_quality if min_quality is not None else 20,
+                   sliding_window_width if sliding_window_width is not None else 4, run_trim, do_count)
+
+    print_log("Processing reads...")
+    ins_pairs = []                       # (ref_pos, string) of every insertion event (host copy of each batch is at hand)
+    pending = []
+    s_i = None
+    read_base = 0
+
+    def flush():
+        nonlocal read_base
+        if not pending:
+            return
+        batch = ReadBatch.from_segments([r.to_segment() for r in pending])
+        res = eng.process(batch, read_base=read_base)
+        bad = np.nonzero(res.status)[0]
+        if len(bad):                      # the reference dies on the first such read with an uncaught exception
+            _raise_for_status(res.status[bad[0]])
+        if run_trim and writer is not None:
+            for k, r in enumerate(pending):
+                fl = int(res.trim_flags[k])
+                if int(res.ref_len[k]) >= min_length and ((fl & 3) or include_no_primer):      # AmpliPy.py:910
+                    writer.write(r, pos=int(res.new_pos[k]), cigar=res.cigar_ops(k))
+        if do_count:
+            ev = eng.events()
+            new = ev[ev["read"] >= read_base] if read_base else ev
+            ins_pairs.extend(event_strings(batch, new, read_base))
+        read_base += batch.n
+        del pending[:]
+
+    for s_i, rec in enumerate(reader):
+        if s_i % PROGRESS_NUM_READS == 0 and s_i != 0:
+            print_log("Processed %d reads..." % s_i)
+        if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
+            continue
+        pending.append(rec)
+        if len(pending) >= BATCH_READS:
+            flush()
+    flush()
+    if writer is not None:
+        writer.close()
+    reader.close()
+
+    if do_count:
+        cp = calling.call_params(min_depth_consensus if min_depth_consensus is not None else 0,
+                                 min_freq_consensus if min_freq_consensus is not None else 0,
+                                 min_depth_variants if min_depth_variants is not None else 0,
+                                 min_freq_variants if min_freq_variants is not None else 0,
+                                 run_consensus, run_variants)
+        eng.set_reference(ref_seq)
+        res = calling.call(eng, ref_seq, cp, lambda positions: calling.tallies_from_events(ins_pairs, positions))
+        if run_variants:
+            for r in res.records:
+                vcf.write(r)
+            vcf.close()
+        if run_consensus:
+            f = gzip.open(consensus_fn, "wt") if consensus_fn.lower().endswith(".gz") else open(consensus_fn, "w")
+            f.write(">sample\n%s\n" % res.consensus_string(unknown_symbol))
+            f.close()
+    eng.close()
+    if s_i is None:
+        raise NameError("name 's_i' is not defined")       # the reference's behaviour on an empty input (:963)
+    print_log("Finished Processing %d reads" % s_i)
+
+
+def parse_args(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        argv.append("-h")
+    D = DEFAULTS
+    fmt = argparse.ArgumentDefaultsHelpFormatter
+    parser = argparse.ArgumentParser(description="amplipy_amd: AmpliPy's toolkit surface on MI355X", formatter_class=fmt)
+    sub = parser.add_subparsers(dest="command")
+
+    def trim_args(p):
+        p.add_argument("-p", "--primer", required=True, type=str, help="Primer File (BED)")
+        p.add_argument("-r", "--reference", required=True, type=str, help="Reference Genome (FASTA)")
+
+    t = sub.add_parser("trim", formatter_class=fmt)
+    t.add_argument("-i", "--input", required=False, type=str, default="stdin", help="Untrimmed Reads (SAM/BAM)")
+    trim_args(t)
+    t.add_argument("-o", "--output", required=False, type=str, default="stdout", help="Trimmed Reads (SAM/BAM)")
+    t.add_argument("-x", "--primer_pos_offset", required=False, type=int, default=D["primer_pos_offset"], help="Primer position offset")
+    t.add_argument("-ml", "--min_length", required=False, type=int, default=D["min_length"], help="Minimum length of read to retain after trimming")
+    t.add_argument("-mq", "--min_quality", required=False, type=int, default=D["min_quality"], help="Minimum quality threshold")
+    t.add_argument("-s", "--sliding_window_width", required=False, type=int, default=D["sliding_window_width"], help="Width of sliding window")
+    t.add_argument("-e", "--include_no_primer", action="store_true", help="Include reads with no primers")
+
+    v = sub.add_parser("variants", formatter_class=fmt)
+    v.add_argument("-i", "--input", required=False, type=str, default="stdin", help="Trimmed Reads (SAM/BAM)")
+    v.add_argument("-r", "--reference", required=True, type=str, help="Reference Genome (FASTA)")
+    v.add_argument("-o", "--output", required=False, type=str, default="stdout", help="Variant Calls (VCF)")
+    v.add_argument("-mq", "--min_quality", required=False, type=int, default=D["min_quality"], help="Minimum quality threshold")
+    v.add_argument("-mf", "--min_freq", required=False, type=float, default=D["min_freq_variants"], help="Minimum frequency threshold (0-1) to call variant")
+    v.add_argument("-md", "--min_depth", required=False, type=int, default=D["min_depth_variants"], help="Minimum depth to call variant")
+
+    c = sub.add_parser("consensus", formatter_class=fmt)
+    c.add_argument("-i", "--input", required=False, type=str, default="stdin", help="Trimmed Reads (SAM/BAM)")
+    c.add_argument("-r", "--reference", required=True, type=str, help="Reference Genome (FASTA)")
+    c.add_argument("-o", "--output", required=False, type=str, default="stdout", help="Consensus Sequence (FASTA)")
+    c.add_argument("-mq", "--min_quality", required=False, type=int, default=D["min_quality"], help="Minimum quality threshold")
+    c.add_argument("-mf", "--min_freq", required=False, type=float, default=D["min_freq_consensus"], help="Minimum frequency threshold (0-1) to call consensus")
+    c.add_argument("-md", "--min_depth", required=False, type=int, default=D["min_depth_consensus"], help="Minimum depth to call consensus")
+    c.add_argument("-n", "--unknown_symbol", required=False, type=str, default=D["unknown_symbol"], help="Character to print in regions with less than minimum coverage")
+
+    a = sub.add_parser("aio", formatter_class=fmt)
+    a.add_argument("-i", "--input", required=False, type=str, default="stdin", help="Untrimmed Reads (SAM/BAM)")
+    trim_args(a)
+    a.add_argument("-ot", "--output_trimmed_reads", required=True, type=str, help="Trimmed Reads (SAM/BAM)")
+    a.add_argument("-ov", "--output_variants", required=True, type=str, help="Variant Calls (VCF)")
+    a.add_argument("-oc", "--output_consensus", required=True, type=str, help="Consensus Sequence (FASTA)")
+    a.add_argument("-x", "--primer_pos_offset", required=False, type=int, default=D["primer_pos_offset"], help="Primer position offset")
+    a.add_argument("-ml", "--min_length", required=False, type=int, default=D["min_length"], help="Minimum length of read to retain after trimming")
+    a.add_argument("-mq", "--min_quality", required=False, type=int, default=D["min_quality"], help="Minimum quality threshold")
+    a.add_argument("-s", "--sliding_window_width", required=False, type=int, default=D["sliding_window_width"], help="Width of sliding window")
+    a.add_argument("-mfc", "--min_freq_consensus", required=False, type=float, default=D["min_freq_consensus"], help="Minimum frequency threshold (0-1) to call consensus")
+    a.add_argument("-mfv", "--min_freq_variants", required=False, type=float, default=D["min_freq_variants"], help="Minimum frequency threshold (0-1) to call variant")
+    a.add_argument("-mdc", "--min_depth_consensus", required=False, type=int, default=D["min_depth_consensus"], help="Minimum depth to call consensus")
+    a.add_argument("-mdv", "--min_depth_variants", required=False, type=int, default=D["min_depth_variants"], help="Minimum depth to call variant")
+    a.add_argument("-n", "--unknown_symbol", required=False, type=str, default=D["unknown_symbol"], help="Character to print in regions with less than minimum coverage")
+    a.add_argument("-e", "--include_no_primer", action="store_true", help="Include reads with no primers")
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.command == "trim":
+        run_amplipy(untrimmed_reads_fn=args.input, primer_fn=args.primer, reference_fn=args.reference,
+                    trimmed_reads_fn=args.output, primer_pos_offset=args.primer_pos_offset, min_length=args.min_length,
+                    min_quality=args.min_quality, sliding_window_width=args.sliding_window_width,
+                    include_no_primer=args.include_no_primer, run_trim=True)
+    elif args.command == "variants":
+        run_amplipy(trimmed_reads_fn=args.input, reference_fn=args.reference, variants_fn=args.output,
+                    min_quality=args.min_quality, min_freq_variants=args.min_freq, min_depth_variants=args.min_depth,
+                    run_variants=True)
+    elif args.command == "consensus":
+        run_amplipy(trimmed_reads_fn=args.input, reference_fn=args.reference, consensus_fn=args.output,
+                    min_quality=args.min_quality, min_freq_consensus=args.min_freq, min_depth_consensus=args.min_depth,
+                    unknown_symbol=args.unknown_symbol, run_consensus=True)
+    elif args.command == "aio":
+        run_amplipy(untrimmed_reads_fn=args.input, primer_fn=args.primer, reference_fn=args.reference,
+                    trimmed_reads_fn=args.output_trimmed_reads, variants_fn=args.output_variants,
+                    consensus_fn=args.output_consensus, primer_pos_offset=args.primer_pos_offset,
+                    min_length=args.min_length, min_quality=args.min_quality,
+                    sliding_window_width=args.sliding_window_width, min_freq_consensus=args.min_freq_consensus,
+                    min_freq_variants=args.min_freq_variants, min_depth_consensus=args.min_depth_consensus,
+                    min_depth_variants=args.min_depth_variants, unknown_symbol=args.unknown_symbol,
+                    include_no_primer=args.include_no_primer, run_trim=True, run_variants=True, run_consensus=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""Multi-GPU plumbing: how reads are partitioned over ranks and how results are stitched.
+
+The hot path shards naturally: trimming is per read, counts are integer sums over reads
+(associative and commutative, so any partition gives bit-identical tables) and insertion
+events are a multiset union.  One process per GPU; the only data-path collective is ONE
+reduce (sum, uint32) of the device table -- 7 x ref_len words: counts [ref_len][6] followed
+by the insertion-event tally [ref_len] -- over RCCL/xGMI (torch.distributed backend "nccl";
+"gloo" on CPU in the tests).  Insertion strings are only needed for the positions the calling
+kernel flags, so they travel as a small object gather to rank 0.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def amplicon_range(n_amplicons, rank, world):
+    """Contiguous run of amplicons owned by ``rank`` (coordinate-range partition)."""
+    return (n_amplicons * rank) // world, (n_amplicons * (rank + 1)) // world
+
+
+def shard_bounds(batch, world):
+    """Split a coordinate-sorted batch into ``world`` contiguous slices with (nearly) equal BASE
+    counts (not read counts: reads differ in length).  Returns world+1 row indices."""
+    cum = np.concatenate([[0], np.cumsum(batch.lseq.astype(np.int64))])
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, total * k // world, side="left")) for k in range(world + 1)]
+    cuts[0], cuts[-1] = 0, batch.n
+    return cuts
+
+
+def reduce_table(dist, table, dst=0):
+    """Sum the device table (torch int32/uint32-as-int32 tensor) onto ``dst``."""
+    dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
+
+
+def gather_relevant_events(dist, rank, world, pairs, dst=0):
+    """Union of [(ref_pos, string)] lists on ``dst`` (other ranks get [])."""
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(pairs, gathered, dst=dst)
+    return [p for part in gathered for p in part] if rank == dst else []
+
+
+def agree_on_positions(dist, rank, positions, src=0):
+    """Broadcast the list of insertion-relevant positions decided on ``src``."""
+    box = [positions if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

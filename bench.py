@@ -58,7 +58,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    from amplipy_amd import abi, calling, lib, synth, synth_torch
+    from amplipy_amd import abi, calling, lib, parallel, synth, synth_torch
 
     genome = synth.make_genome()
     primers, amps = synth.make_artic_scheme()
@@ -66,8 +66,7 @@ def main():
     ref_seq = synth.genome_string(genome)
     n_reads = synth.reads_for_depth(args.depth)
     # range partition by coordinate: rank r owns a contiguous run of amplicons
-    a_lo = (amps.shape[0] * rank) // world
-    a_hi = (amps.shape[0] * (rank + 1)) // world
+    a_lo, a_hi = parallel.amplicon_range(amps.shape[0], rank, world)
     t_gen = time.time()
     batch = synth_torch.make_amplicon_batch_device(genome, amps[a_lo:a_hi], n_reads, seed=1000 + rank, device=dev)
     torch.cuda.synchronize()
@@ -101,9 +100,7 @@ def main():
         strings = eng.event_strings_device(rd, ev[keep]) if keep.any() else []
         pairs = list(zip(ev["ref_pos"][keep].tolist(), strings))
         if dist is not None:
-            gathered = [None] * world
-            dist.gather_object(pairs, gathered if rank == 0 else None, dst=0)
-            pairs = [p for part in gathered for p in part] if rank == 0 else []
+            pairs = parallel.gather_relevant_events(dist, rank, world, pairs)
         return calling.tallies_from_events(pairs, positions)
 
     scan_ms = []
@@ -113,22 +110,22 @@ def main():
         eng.reset()
         eng.process_device(rd, 0, dev_out)
         if dist is not None:
-            dist.reduce(table, dst=0, op=dist.ReduceOp.SUM)
+            parallel.reduce_table(dist, table, dst=0)
         if dist is None:
             last["call"] = res = calling.call(eng, ref_seq, cp, ins_provider)
             last["consensus"] = res.consensus_string("N")
         else:
             # relevant positions need every rank's insertion events: agree on the list first
-            rel = [None]
+            rel = None
             if rank == 0:
                 pcs = eng.call_positions(cp)
-                rel[0] = np.nonzero(pcs[0]["flags"] & abi.CALL_INS_RELEVANT)[0].tolist()
-            dist.broadcast_object_list(rel, src=0)
+                rel = np.nonzero(pcs[0]["flags"] & abi.CALL_INS_RELEVANT)[0].tolist()
+            rel = parallel.agree_on_positions(dist, rank, rel)
             if rank == 0:
                 last["call"] = res = calling.call(eng, ref_seq, cp, ins_provider, positions=pcs)
                 last["consensus"] = res.consensus_string("N")
-            elif rel[0]:
-                ins_provider(set(rel[0]))
+            elif rel:
+                ins_provider(set(rel))
         scan_ms.append(eng.last_kernel_ms()[1])
 
     for _ in range(args.warmup):

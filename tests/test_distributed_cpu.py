@@ -1,0 +1,89 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo).  The GPU kernels cannot run here,
+so each rank computes its shard with the CPU oracle; what is under test is the host logic that
+the bench and run_amplipy use across ranks: the coordinate-range partition, the single reduce
+of the 7 x ref_len table, and the agreement / gather protocol for insertion-relevant positions."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from amplipy_amd import parallel, synth
+from amplipy_amd.insertions import event_strings
+from oracle import oracle
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_reads, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+        pr = [(s, e) for s, e, _ in primers]
+        mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, 0)
+        batch = synth.make_amplicon_batch(g, amps, n_reads, seed=77)     # same batch on every rank
+        cuts = parallel.shard_bounds(batch, world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        mine = batch.slice(lo, hi)
+        r = oracle.process(mine, g.size, mn, mx, mpl, 20, 4, read_base=lo)
+        table = np.zeros(g.size * 7, np.int64)
+        table[:g.size * 6] = r.counts.reshape(-1)
+        np.add.at(table[g.size * 6:], r.events["ref_pos"], 1)
+        t = torch.from_numpy(table.astype(np.int32))
+        parallel.reduce_table(dist, t, dst=0)
+        # pretend every 97th position with events is insertion-relevant
+        rel = None
+        if rank == 0:
+            tally = t.numpy()[g.size * 6:]
+            rel = [int(p) for p in np.nonzero(tally)[0][::97]]
+        rel = parallel.agree_on_positions(dist, rank, rel)
+        ev = r.events[np.isin(r.events["ref_pos"], rel)]
+        ev_local = ev.copy(); ev_local["read"] -= lo
+        pairs = event_strings(mine, ev_local)
+        allpairs = parallel.gather_relevant_events(dist, rank, world, pairs)
+        if rank == 0:
+            np.savez(out_path, table=t.numpy(), rel=np.array(rel), pairs=np.array(sorted(allpairs), dtype=object),
+                     cuts=np.array(cuts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_reduce_matches_single_process(tmp_path, world):
+    n_reads = 6000
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n_reads, out), nprocs=world, join=True)
+    got = np.load(out, allow_pickle=True)
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    pr = [(s, e) for s, e, _ in primers]
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, 0)
+    batch = synth.make_amplicon_batch(g, amps, n_reads, seed=77)
+    ref = oracle.process(batch, g.size, mn, mx, mpl, 20, 4)
+    table = got["table"].view(np.uint32)
+    assert np.array_equal(table[:g.size * 6].reshape(g.size, 6), ref.counts)
+    tally = np.zeros(g.size, np.int64); np.add.at(tally, ref.events["ref_pos"], 1)
+    assert np.array_equal(table[g.size * 6:], tally.astype(np.uint32))
+    rel = set(int(p) for p in got["rel"])
+    want = sorted(p for p in event_strings(batch, ref.events) if p[0] in rel)
+    assert [tuple(x) for x in got["pairs"]] == want
+    cuts = got["cuts"]
+    assert cuts[0] == 0 and cuts[-1] == batch.n and all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+
+
+def test_shard_bounds_balance_bases():
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    from amplipy_amd.batch import ReadBatch
+    segs = synth.make_mixed_segments(g, amps, 3000, seed=3)
+    b = ReadBatch.from_segments(segs)
+    for world in (2, 4, 8):
+        cuts = parallel.shard_bounds(b, world)
+        bases = [int(b.lseq[a:c].sum()) for a, c in zip(cuts[:-1], cuts[1:])]
+        assert sum(bases) == b.total_bases()
+        assert max(bases) - min(bases) <= 2 * 300      # within a couple of reads of each other
+    assert parallel.amplicon_range(98, 0, 8) == (0, 12) and parallel.amplicon_range(98, 7, 8)[1] == 98
