@@ -56,6 +56,9 @@ class AmpCallParams(C.Structure):
 POS_CALL_DTYPE = np.dtype([("total_depth", "<u4"), ("ref_count", "<u4"), ("order", "<u4"), ("consensus_sym", "i1"),
                            ("flags", "u1"), ("alt_mask", "u1"), ("pad", "u1")])
 CALL_VARIANT, CALL_GT_HAS_REF, CALL_INS_RELEVANT = 1, 2, 4
+VAR_REC_DTYPE = np.dtype([("pos", "<i4"), ("total_depth", "<u4"), ("ref_count", "<u4"), ("n_alt", "u1"),
+                          ("gt_has_ref", "u1"), ("alt_col", "u1", (6,)), ("alt_count", "<u4", (6,))])
+assert VAR_REC_DTYPE.itemsize == 44
 
 
 def ptr(a):

@@ -44,8 +44,8 @@ class CallResult:
                    (text in ``consensus_ins[pos]``)
     var_pos        int32[V] positions with a VCF record, ascending
     var_total / var_ref_count  uint32[V];  var_gt_ref  bool[V] (GT includes 0)
-    var_nalt       int8[V];  var_alt_col int8[V,5] (columns of the base-symbol ALTs, -1 pad);
-                   var_alt_count uint32[V,5]
+    var_nalt       int8[V];  var_alt_col int8[V,6] (columns of the base-symbol ALTs, -1 pad);
+                   var_alt_count uint32[V,6]
     ``extra``      {pos: VariantRecord or None} for positions finished from insertion alleles
                    (they override the arrays; None = no record)
     """
@@ -139,6 +139,14 @@ def _decide(pos, ref_symbol, total, ranked, cp):
     return consensus, record
 
 
+def result_from_compact(ref_seq, cp, cons, vr):
+    """CallResult from the arrays of Engine.call_compact when no position needs insertion alleles."""
+    if not cp.run_consensus:
+        cons = np.full(cons.size, -1, np.int8)
+    return CallResult(ref_seq, cons, {}, vr["pos"], vr["total_depth"], vr["ref_count"], vr["gt_has_ref"] != 0,
+                      vr["n_alt"].astype(np.int8), vr["alt_col"].view(np.int8), vr["alt_count"], {}, None, 0)
+
+
 def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False, positions=None):
     """Run calling for the state accumulated in ``engine``.
 
@@ -146,6 +154,11 @@ def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False, positions
     supplies the insertion-allele tallies of the flagged positions (only called when needed).
     ``positions``: a (records, n_relevant) pair already obtained from engine.call_positions.
     """
+    if positions is None and not want_alleles and not cp.full_ranking:
+        # fast path: everything was decided and packed on the device
+        cons, vr, rel = engine.call_compact(cp)
+        if rel.size == 0:
+            return result_from_compact(ref_seq, cp, cons, vr)
     pc, n_rel = positions if positions is not None else engine.call_positions(cp)
     flags = pc["flags"]
     consensus_sym = pc["consensus_sym"].copy() if cp.run_consensus else np.full(engine.ref_len, -1, np.int8)
@@ -156,8 +169,8 @@ def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False, positions
     if var_pos.size or n_rel or want_alleles:
         counts = engine.counts()
     V = var_pos.size
-    alt_col = np.full((V, 5), -1, np.int8)
-    alt_cnt = np.zeros((V, 5), np.uint32)
+    alt_col = np.full((V, 6), -1, np.int8)
+    alt_cnt = np.zeros((V, 6), np.uint32)
     nalt = np.zeros(V, np.int8)
     if V:
         order = pc["order"][var_pos]

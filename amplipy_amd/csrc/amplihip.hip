@@ -283,6 +283,52 @@ __global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__re
     out[p] = o;
 }
 
+// Packs the outcome of k_call for the host: consensus column per position, the variant records in
+// ascending position (insertion-relevant positions excluded: the host finishes those), and the list
+// of insertion-relevant positions.  One block; each thread owns a contiguous run of positions.
+__global__ void __launch_bounds__(1024)
+k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__ counts, int32_t ref_len,
+               int8_t *__restrict__ cons, amp_var_rec *__restrict__ vars, int32_t *__restrict__ rel, unsigned long long *n_out) {
+    __shared__ uint32_t sv[1024], sr[1024];
+    const int tid = threadIdx.x;
+    const int32_t per = (ref_len + 1023) / 1024;
+    const int32_t p0 = tid * per, p1 = p0 + per < ref_len ? p0 + per : ref_len;
+    uint32_t nv = 0, nr = 0;
+    for (int32_t p = p0; p < p1; ++p) {
+        const uint8_t f = pc[p].flags;
+        if (f & AMP_CALL_INS_RELEVANT) ++nr; else if (f & AMP_CALL_VARIANT) ++nv;
+    }
+    sv[tid] = nv; sr[tid] = nr;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t a = tid >= o ? sv[tid - o] : 0u, b = tid >= o ? sr[tid - o] : 0u;
+        __syncthreads();
+        sv[tid] += a; sr[tid] += b;
+        __syncthreads();
+    }
+    uint32_t ov = sv[tid] - nv, orl = sr[tid] - nr;
+    if (tid == 1023) { n_out[0] = sv[1023]; n_out[1] = sr[1023]; }
+    for (int32_t p = p0; p < p1; ++p) {
+        const amp_pos_call c = pc[p];
+        cons[p] = c.consensus_sym;
+        if (c.flags & AMP_CALL_INS_RELEVANT) { rel[orl++] = p; continue; }
+        if (!(c.flags & AMP_CALL_VARIANT)) continue;
+        amp_var_rec v;
+        v.pos = p; v.total_depth = c.total_depth; v.ref_count = c.ref_count;
+        v.gt_has_ref = (c.flags & AMP_CALL_GT_HAS_REF) ? 1 : 0;
+        uint8_t na = 0;
+        for (int k = 0; k < 6; ++k) { v.alt_col[k] = 0xFF; v.alt_count[k] = 0; }
+        for (int k = 0; k < 6; ++k) {
+            if ((c.alt_mask >> k) & 1u) {
+                const uint32_t col = (c.order >> (3 * k)) & 7u;
+                v.alt_col[na] = (uint8_t)col; v.alt_count[na] = counts[(size_t)p * AMP_NSYM + col]; ++na;
+            }
+        }
+        v.n_alt = na;
+        vars[ov++] = v;
+    }
+}
+
 // Copies the text of insertion events (SEQ[q_from:q_to], A:736-738, upper-cased like A:702)
 // out of a device-resident batch: one lane per event.
 __global__ void k_event_strings(amp_dev_reads rd, uint64_t read_base, int64_t n_ev, const amp_ins_event *__restrict__ ev,
@@ -733,6 +779,36 @@ int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out,
     HIPCHK(c, hipMemcpyAsync(&nr, &c->d_ctr[4], sizeof(nr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (n_relevant) *n_relevant = (int64_t)nr;
+    return AMP_OK;
+}
+
+int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, amp_var_rec *vars, int64_t vars_cap,
+                     int64_t *n_vars, int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant) {
+    if (!c || !pr || !consensus || !n_vars || !n_relevant || vars_cap < 0 || relevant_cap < 0) return AMP_EINVAL;
+    if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
+    Guard g(c);
+    const int32_t G = c->ref_len;
+    const size_t off_cons = (size_t)G * sizeof(amp_pos_call);
+    const size_t off_vars = (off_cons + (size_t)G + 63) & ~(size_t)63;
+    const size_t off_rel = off_vars + (size_t)G * sizeof(amp_var_rec);
+    HIPCHK(c, c->call_buf.ensure(off_rel + (size_t)G * 4));
+    uint8_t *base = c->call_buf.as<uint8_t>();
+    amp_pos_call *d_pc = (amp_pos_call *)base;
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 3 * sizeof(unsigned long long), c->stream));
+    k_call<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, &c->d_ctr[4]);
+    HIPCHK(c, hipGetLastError());
+    k_call_compact<<<1, 1024, 0, c->stream>>>(d_pc, c->d_counts, G, (int8_t *)(base + off_cons), (amp_var_rec *)(base + off_vars),
+                                              (int32_t *)(base + off_rel), &c->d_ctr[5]);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long nn[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(nn, &c->d_ctr[5], sizeof(nn), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(consensus, base + off_cons, (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_vars = (int64_t)nn[0]; *n_relevant = (int64_t)nn[1];
+    if ((int64_t)nn[0] > vars_cap || (int64_t)nn[1] > relevant_cap) return AMP_EOVERFLOW;
+    if (nn[0] && vars) HIPCHK(c, hipMemcpyAsync(vars, base + off_vars, (size_t)nn[0] * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+    if (nn[1] && relevant) HIPCHK(c, hipMemcpyAsync(relevant, base + off_rel, (size_t)nn[1] * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMP_OK;
 }
 

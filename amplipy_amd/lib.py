@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact",
 ]
 
 
@@ -200,6 +200,18 @@ class Engine:
         self._chk(self.L.amp_call_positions(self.h, C.byref(params), C.c_void_p(abi.ptr(out)), C.byref(nr)),
                   "amp_call_positions")
         return out, int(nr.value)
+
+    def call_compact(self, params):
+        """amp_call_compact -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R])."""
+        G = self.ref_len
+        if not hasattr(self, "_cc"):
+            self._cc = (np.zeros(G, np.int8), np.zeros(G, abi.VAR_REC_DTYPE), np.zeros(G, np.int32))
+        cons, vars_, rel = self._cc
+        nv = C.c_int64(0); nr = C.c_int64(0)
+        self._chk(self.L.amp_call_compact(self.h, C.byref(params), C.c_void_p(abi.ptr(cons)), C.c_void_p(abi.ptr(vars_)),
+                                          C.c_int64(G), C.byref(nv), C.c_void_p(abi.ptr(rel)), C.c_int64(G), C.byref(nr)),
+                  "amp_call_compact")
+        return cons.copy(), vars_[:nv.value].copy(), rel[:nr.value].copy()
 
     def event_strings_device(self, dev_reads, events, read_base=0):
         """Strings of ``events`` (INS_EVENT_DTYPE) taken from a device-resident batch."""

@@ -118,11 +118,15 @@ def main():
             # relevant positions need every rank's insertion events: agree on the list first
             rel = None
             if rank == 0:
-                pcs = eng.call_positions(cp)
-                rel = np.nonzero(pcs[0]["flags"] & abi.CALL_INS_RELEVANT)[0].tolist()
+                cons, vr, relpos = eng.call_compact(cp)
+                rel = relpos.tolist()
             rel = parallel.agree_on_positions(dist, rank, rel)
             if rank == 0:
-                last["call"] = res = calling.call(eng, ref_seq, cp, ins_provider, positions=pcs)
+                if rel:
+                    res = calling.call(eng, ref_seq, cp, ins_provider, positions=eng.call_positions(cp))
+                else:
+                    res = calling.result_from_compact(ref_seq, cp, cons, vr)
+                last["call"] = res
                 last["consensus"] = res.consensus_string("N")
             elif rel:
                 ins_provider(set(rel))

@@ -242,11 +242,29 @@ typedef struct amp_pos_call {
     uint8_t pad;
 } amp_pos_call;
 
+/* One VCF record decided on the device (positions not flagged AMP_CALL_INS_RELEVANT). */
+typedef struct amp_var_rec {
+    int32_t pos;            /* 0-based; VCF POS = pos + 1 (AmpliPy.py:947) */
+    uint32_t total_depth;   /* DP */
+    uint32_t ref_count;     /* REF_DP */
+    uint8_t n_alt;
+    uint8_t gt_has_ref;     /* GT = 0/1/../n_alt when set, 1/../n_alt otherwise (AmpliPy.py:948-951) */
+    uint8_t alt_col[6];     /* ALT symbols in ranked order: columns A C G T N - = 0..5 */
+    uint32_t alt_count[6];  /* ALT_DP; ALT_FREQ = alt_count / total_depth as IEEE doubles */
+} amp_var_rec;
+
 /* ASCII reference sequence, length ref_len, exactly as read from the FASTA (REF is compared
  * un-upper-cased, AmpliPy.py:923). */
 int amp_set_reference(amp_ctx *ctx, const uint8_t *ref_ascii);
 int amp_call_positions(amp_ctx *ctx, const amp_call_params *params, amp_pos_call *out /* host [ref_len] */,
                        int64_t *n_relevant);
+/* The same decisions packed for the host: consensus column per position (-1 unknown), the
+ * variant records in ascending position, and the insertion-relevant positions (whose
+ * consensus / record the host finishes).  Returns AMP_EOVERFLOW (with the needed counts) when
+ * a capacity is too small; ref_len entries always suffice. */
+int amp_call_compact(amp_ctx *ctx, const amp_call_params *params, int8_t *consensus /* [ref_len] */,
+                     amp_var_rec *vars, int64_t vars_cap, int64_t *n_vars,
+                     int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant);
 /* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
  * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host. */
 int amp_event_strings(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int64_t n_events,
