@@ -52,7 +52,7 @@ constexpr uint32_t DEFER_INDELS = 0x40000000u;        // match bases counted by 
 constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 
 // per-read state words kept in LDS for the chunk lanes
-enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_T0, S_T1, S_WORDS };   // S_T0/1: 8 quality bytes for the partial windows
+enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_WORDS };
 enum : int { G_OFF8, G_M, G_R0, G_RC, G_WORDS };   // per-segment words; G_RC = owner lane | chunk base << 8
 
 struct WaveLds {
@@ -255,6 +255,204 @@ __device__ void classify(const CB &c, int n, int32_t lseq, bool &regular, bool &
     plain = regular && nother == 0;
 }
 
+// ---- chunk phases -------------------------------------------------------------------------------
+// Both chunk loops run as blocks of T_UNROLL chunks per lane: stage A issues every global load of
+// the block, stage B consumes them.  FULL = every lane of the wave has T_UNROLL chunks (no bounds
+// tests); the last, partial block of a round runs the checked variant.  Loads are unconditional:
+// a chunk may read up to 8 bytes past its own 8 bytes, so `qual` and `seq` need 16 bytes of
+// readable slack after the last read (documented in amplihip.h).
+
+typedef short amp_short2 __attribute__((ext_vector_type(2)));
+
+// bit b set: the W-byte window starting at byte b of the 16-byte group sums to less than thr
+template <int W>
+__device__ __forceinline__ uint32_t window_fail_bits16(const uint2 lo, const uint2 hi, uint32_t thr) {
+    if (W == 4) {
+        // four sliding 4-byte sums per instruction, packed as u16
+        const uint64_t a = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)lo.x | ((uint64_t)lo.y << 32), 0u, 0ull);
+        const uint64_t b = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)lo.y | ((uint64_t)hi.x << 32), 0u, 0ull);
+        const uint32_t t2 = thr | (thr << 16);
+        const uint32_t d[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            amp_short2 x = __builtin_bit_cast(amp_short2, d[k]) - __builtin_bit_cast(amp_short2, t2);   // negative: sum < thr
+            const uint32_t u = __builtin_bit_cast(uint32_t, x);
+            m |= ((u >> 15) & 1u) << (2 * k);
+            m |= (u >> 31) << (2 * k + 1);
+        }
+        return m;
+    }
+    const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+    return window_fail_bits<W>(w, thr);
+}
+
+struct ChunkEnv {
+    const lds_u8 *cmap;
+    lds_u32 *st;
+    lds_u32 *seg;
+    lds_u32 *win;
+    lds_u32 *lut;
+    const uint8_t *qual;
+    const uint8_t *seq;
+    uint32_t *counts;
+    int32_t win_base;
+    uint32_t wlim, G;
+    int32_t mq;
+};
+
+template <int W, bool FULL>
+__device__ __forceinline__ void p2_block(const ChunkEnv &E, uint32_t cc, uint32_t lim, uint32_t base, uint32_t thr) {
+    uint2 a0[T_UNROLL], a1[T_UNROLL];
+    uint32_t rr[T_UNROLL];
+    int32_t jj[T_UNROLL];
+#pragma unroll
+    for (int u = 0; u < T_UNROLL; ++u) {
+        const uint32_t c = cc + 64u * u;
+        a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0); rr[u] = 0; jj[u] = 0;
+        if (FULL || c < lim) {
+            const uint32_t r = E.cmap[c];
+            const int32_t rlo = (int32_t)(E.st[S_LOHI * TILE + r] & 0xFFFFu);
+            const int32_t j0 = ((int32_t)(c + base - E.st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
+            const uint8_t *qp = E.qual + (int64_t)E.st[S_OFF8 * TILE + r] * 8 + j0;
+            a0[u] = *(const uint2 *)qp;
+            a1[u] = *(const uint2 *)(qp + 8);
+            rr[u] = r; jj[u] = j0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < T_UNROLL; ++u) {
+        if (FULL || cc + 64u * u < lim) {
+            const uint32_t r = rr[u];
+            const int32_t j0 = jj[u];
+            const uint32_t lohi = E.st[S_LOHI * TILE + r];
+            const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
+            uint32_t fail = window_fail_bits16<W>(a0[u], a1[u], thr);
+            int32_t blo = rlo - j0, bhi = rhi - W - j0;          // starts j0+b must lie in [rlo, rhi - W]
+            blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
+            fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
+            if (fail) {
+                const bool rv = E.st[S_REV * TILE + r] != 0;
+                const uint32_t vf = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);            // first failing window start
+                const uint32_t vr = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + W - rlo);  // last failing window end
+                __hip_atomic_fetch_min(E.st + S_FF * TILE + r, rv ? vr : vf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void p2_round(const ChunkEnv &E, int lane, uint32_t lim, uint32_t base, uint32_t thr) {
+    const uint32_t step = 64u * T_UNROLL;
+    const uint32_t nfull = (lim / step) * step;
+    uint32_t cc = (uint32_t)lane;
+    for (; cc < nfull; cc += step) p2_block<W, true>(E, cc, lim, base, thr);
+    if (nfull < lim) p2_block<W, false>(E, nfull + (uint32_t)lane, lim, base, thr);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t cc, uint32_t lim, uint32_t base) {
+    uint2 aq[T_UNROLL];
+    uint32_t as_[T_UNROLL], sgs[T_UNROLL];
+    int32_t jj[T_UNROLL];
+#pragma unroll
+    for (int u = 0; u < T_UNROLL; ++u) {
+        const uint32_t c = cc + 64u * u;
+        aq[u] = make_uint2(0, 0); as_[u] = 0; sgs[u] = 0; jj[u] = 0;
+        if (FULL || c < lim) {
+            const uint32_t sg = E.cmap[c];
+            const int32_t m0 = (int32_t)(E.seg[G_M * T_SEGCAP + sg] & 0xFFFFu);
+            const int32_t j0 = ((int32_t)(c + base - (E.seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
+            const int64_t rb = (int64_t)E.seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
+            aq[u] = *(const uint2 *)(E.qual + rb);
+            as_[u] = *(const uint32_t *)(E.seq + (rb >> 1));
+            sgs[u] = sg; jj[u] = j0;
+        }
+    }
+    const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
+#pragma unroll
+    for (int u = 0; u < T_UNROLL; ++u) {
+        if (FULL || cc + 64u * u < lim) {
+            const uint32_t sg = sgs[u];
+            const uint32_t mm = E.seg[G_M * T_SEGCAP + sg];
+            const int32_t m0 = (int32_t)(mm & 0xFFFFu), m1 = (int32_t)(mm >> 16);
+            const int32_t j0 = jj[u];
+            const int32_t d0 = (int32_t)E.seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - E.win_base;   // window offset of base 0
+            const uint2 qw = aq[u];
+            uint32_t sw = as_[u];
+            // per-byte flags (bit 7): base inside [m0, m1) and quality >= min_quality
+            int32_t klo = m0 - j0, khi = m1 - j0;
+            klo = klo < 0 ? 0 : klo; khi = khi > 8 ? 8 : khi;
+            const uint64_t inm = (khi >= 8 ? ~0ull : ((1ull << (khi * 8)) - 1ull)) & ~((1ull << (klo * 8)) - 1ull);
+            uint32_t ok0, ok1;
+            if (E.mq <= 128) {
+                const uint32_t mqb = (uint32_t)E.mq * 0x01010101u;
+                ok0 = ((((qw.x & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.x) & 0x80808080u;
+                ok1 = ((((qw.y & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.y) & 0x80808080u;
+            } else {
+                ok0 = ok1 = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    ok0 |= (((qw.x >> (8 * b)) & 0xFFu) >= (uint32_t)E.mq ? 0x80u : 0u) << (8 * b);
+                    ok1 |= (((qw.y >> (8 * b)) & 0xFFu) >= (uint32_t)E.mq ? 0x80u : 0u) << (8 * b);
+                }
+            }
+            ok0 &= (uint32_t)inm; ok1 &= (uint32_t)(inm >> 32);
+            // a counted base with a code outside A C G T N, or a chunk that leaves the LDS window: careful path
+            sw = ((sw & 0x0F0F0F0Fu) << 4) | ((sw >> 4) & 0x0F0F0F0Fu);   // base k at bits [4k, 4k+4)
+            uint32_t pc = sw - ((sw >> 1) & 0x55555555u);
+            pc = (pc & 0x33333333u) + ((pc >> 2) & 0x33333333u);         // per-nibble popcount (0..4)
+            const uint32_t good = (pc ^ (pc >> 2)) & ~(pc >> 1) & 0x11111111u;   // popcount 1 (A C G T) or 4 (N)
+            const uint32_t nm = (khi >= 8 ? 0xFFFFFFFFu : ((1u << (khi * 4)) - 1u)) & ~((1u << (klo * 4)) - 1u);
+            const bool safe = (~good & nm & 0x11111111u) == 0u && (uint32_t)d0 <= E.wlim - 8u && E.wlim >= 8u;
+            if (safe) {
+                // rotate the 8 bases by `rot` so that lanes serviced together spread over the banks
+                const uint32_t oa = (rot & 4u) ? ok1 : ok0, ob = (rot & 4u) ? ok0 : ok1;
+                const uint32_t sh = (rot & 3u) * 8u;
+                const uint32_t k0 = __builtin_amdgcn_alignbit(ob, oa, sh), k1 = __builtin_amdgcn_alignbit(oa, ob, sh);
+                const uint32_t sr = __builtin_amdgcn_alignbit(sw, sw, rot * 4u);
+                lds_u8 *const wbase = (lds_u8 *)E.win + (uint32_t)d0 * 4u;
+                uint32_t plane[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {    // all eight table reads first: they cannot move past the atomics
+                    const uint32_t code4 = b == 0 ? (sr << 2) & 0x3Cu : (sr >> (4 * b - 2)) & 0x3Cu;
+                    plane[b] = *(lds_u32 *)((lds_u8 *)E.lut + code4);
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t val = ((b < 4 ? k0 : k1) >> ((b & 3) * 8 + 7)) & 1u;
+                    const uint32_t bb4 = ((rot + (uint32_t)b) & 7u) * 4u;
+                    lds_add((lds_u32 *)(wbase + plane[b] + bb4), val);
+                }
+            } else {
+                bool bad = false;
+#pragma unroll 1
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t okb = ((b < 4 ? ok0 : ok1) >> ((b & 3) * 8 + 7)) & 1u;
+                    if (!okb) continue;
+                    const uint32_t col = col_of_code((sw >> (4 * b)) & 15u);
+                    const int32_t rp = E.win_base + d0 + b;
+                    const uint32_t d = (uint32_t)(d0 + b);
+                    if (col > 4u || (uint32_t)rp >= E.G) bad = true;
+                    else if (d < (uint32_t)T_W) lds_add(E.win + col * T_W + d, 1u);
+                    else atomicAdd(&E.counts[(size_t)rp * AMP_NSYM + col], 1u);
+                }
+                if (bad) E.st[S_ERR * TILE + (E.seg[G_RC * T_SEGCAP + sg] & 0xFFu)] = 1u;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void p4_round(const ChunkEnv &E, int lane, uint32_t lim, uint32_t base) {
+    const uint32_t step = 64u * T_UNROLL;
+    const uint32_t nfull = (lim / step) * step;
+    uint32_t cc = (uint32_t)lane;
+    for (; cc < nfull; cc += step) p4_block<true>(E, lane, cc, lim, base);
+    if (nfull < lim) p4_block<false>(E, lane, nfull + (uint32_t)lane, lim, base);
+}
+
 // ---------------------------------------------------------------------------------------
 template <bool STAMPS>
 __global__ void __launch_bounds__(T_WAVES * 64)
@@ -310,6 +508,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             int64_t lim = (int64_t)P.ref_len - win_base;
             tc.wlim = lim <= 0 ? 0u : (lim > T_W ? (uint32_t)T_W : (uint32_t)lim);
         }
+        const ChunkEnv env{cmap, st, seg, win, lut, rd.qual, rd.seq, counts, win_base, tc.wlim, (uint32_t)P.ref_len, mq};
         const int64_t tile = t0 + wave;
         if (tile >= tile_end) continue;
 
@@ -347,6 +546,16 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 }
             }
         }
+        // the 3' end's shrinking windows (A:575-576, A:637-638) need at most W-1 bytes; fetch them now so that
+        // they have landed when P3 wants them
+        uint2 tw0 = make_uint2(0, 0), tw1 = make_uint2(0, 0);
+        int32_t tab = 0;
+        if (mine && can_q) {
+            const int32_t first = (rev || qlen < Wd) ? lo : lo + qlen - Wd + 1;
+            tab = first & ~7;
+            tw0 = *(const uint2 *)(qual + tab);
+            tw1 = *(const uint2 *)(qual + tab + 8);
+        }
         // full windows start at aligned-quality indices [0, qlen - W]; chunks are 8 starts wide
         const bool par_scan = mine && can_q && Wd <= 8 && (phases & 2u);
         const int32_t hi = lo + qlen;
@@ -371,58 +580,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             wave_sync();
             const uint32_t lim = total2 - base < (uint32_t)T_MAPCAP ? total2 - base : (uint32_t)T_MAPCAP;
-            for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
-                // stage A: all global loads of T_UNROLL chunks (only the data stays live)
-                uint2 a0[T_UNROLL], a1[T_UNROLL];
-#pragma unroll
-                for (int u = 0; u < T_UNROLL; ++u) {
-                    const uint32_t c = cc + 64u * u;
-                    a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0);
-                    if (c < lim) {
-                        const uint32_t r = cmap[c];
-                        const uint32_t lohi = st[S_LOHI * TILE + r];
-                        const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
-                        const int32_t j0 = ((int32_t)(c + base - st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
-                        const uint8_t *qp = rd.qual + (int64_t)st[S_OFF8 * TILE + r] * 8 + j0;
-                        a0[u] = *(const uint2 *)qp;
-                        if (j0 + 8 < rhi) a1[u] = *(const uint2 *)(qp + 8);
-                    }
-                }
-                // stage B: window sums and the per-read first / last failing window
-#pragma unroll
-                for (int u = 0; u < T_UNROLL; ++u) {
-                    const uint32_t c = cc + 64u * u;
-                    if (c < lim) {
-                        const uint32_t r = cmap[c];
-                        const uint32_t lohi = st[S_LOHI * TILE + r];
-                        const int32_t rlo = (int32_t)(lohi & 0xFFFFu), rhi = (int32_t)(lohi >> 16);
-                        const int32_t j0 = ((int32_t)(c + base - st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
-                        const uint32_t w[4] = {a0[u].x, a0[u].y, a1[u].x, a1[u].y};
-                        uint32_t fail = window_fail_bits_dyn(Wd, w, mqc * (uint32_t)Wd);
-                        const bool rv = st[S_REV * TILE + r] != 0;
-                        {   // the chunk next to the 3' end keeps the bytes of the shrinking windows for P3
-                            const int32_t o = rv ? rlo - j0 : rhi - Wd + 1 - j0;     // first byte wanted
-                            if (rv ? (j0 <= rlo) : (rhi - Wd < j0 + 8)) {
-                                const uint64_t lo64 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi64 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-                                const uint32_t sh = ((uint32_t)o & 7u) * 8u;
-                                uint64_t tb = (uint32_t)o >= 8u ? hi64 : lo64;
-                                if (sh) tb = (lo64 >> sh) | (hi64 << (64u - sh));
-                                st[S_T0 * TILE + r] = (uint32_t)tb;
-                                st[S_T1 * TILE + r] = (uint32_t)(tb >> 32);
-                            }
-                        }
-                        int32_t blo = rlo - j0, bhi = rhi - Wd - j0;    // starts j0+b must lie in [rlo, rhi - W]
-                        blo = blo < 0 ? 0 : blo; bhi = bhi > 7 ? 7 : bhi;
-                        fail &= (0xFFu >> (7 - bhi)) & (0xFFu << blo);
-                        if (fail) {
-                            uint32_t v;
-                            if (rv) v = 0xFFFFu - (uint32_t)(j0 + (31 - __builtin_clz(fail)) + Wd - rlo);   // last failing window end
-                            else v = (uint32_t)(j0 + (__builtin_ffs((int)fail) - 1) - rlo);                                 // first failing window start
-                            __hip_atomic_fetch_min(st + S_FF * TILE + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // one chunk at a time: keeps the live set small
-                }
+            const uint32_t thr = mqc * (uint32_t)Wd;
+            switch (Wd) {
+                case 1: p2_round<1>(env, lane, lim, base, thr); break; case 2: p2_round<2>(env, lane, lim, base, thr); break;
+                case 3: p2_round<3>(env, lane, lim, base, thr); break; case 4: p2_round<4>(env, lane, lim, base, thr); break;
+                case 5: p2_round<5>(env, lane, lim, base, thr); break; case 6: p2_round<6>(env, lane, lim, base, thr); break;
+                case 7: p2_round<7>(env, lane, lim, base, thr); break; default: p2_round<8>(env, lane, lim, base, thr); break;
             }
         }
         wave_sync();
@@ -441,19 +604,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                     // no full window failed: the shrinking windows at the 3' end decide (A:575-576, A:637-638)
                     iq = rev ? 0 : qlen;
                     int32_t acc = 0;
-                    if (qlen >= Wd) {
-                        // stash = 8 bytes starting at lo (reverse) / at hi - W + 1 (forward)
-                        const uint64_t tb = (uint64_t)st[S_T0 * TILE + lane] | ((uint64_t)st[S_T1 * TILE + lane] << 32);
-                        for (int32_t k = 1; k < Wd; ++k) {
-                            acc += (int32_t)((tb >> ((rev ? k - 1 : Wd - 1 - k) * 8)) & 0xFFu);
-                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
-                        }
-                    } else {
-                        const uint8_t *q = qual + lo;
-                        for (int32_t k = 1; k <= qlen; ++k) {
-                            acc += rev ? q[k - 1] : q[qlen - k];
-                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
-                        }
+                    const uint64_t t_lo = (uint64_t)tw0.x | ((uint64_t)tw0.y << 32), t_hi = (uint64_t)tw1.x | ((uint64_t)tw1.y << 32);
+                    const int32_t kmax = qlen < Wd - 1 ? qlen : Wd - 1;
+                    for (int32_t k = 1; k <= kmax; ++k) {
+                        const uint32_t o = (uint32_t)((rev ? lo + k - 1 : hi - k) - tab);      // 0..15
+                        acc += (int32_t)(((o < 8u ? t_lo : t_hi) >> ((o & 7u) * 8u)) & 0xFFu);
+                        if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
                     }
                 }
             } else {
@@ -538,98 +694,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             wave_sync();
             const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
-            for (uint32_t cc = lane; cc < lim; cc += 64 * T_UNROLL) {
-              // stage A: all global loads of T_UNROLL chunks (only the data stays live)
-              uint2 aq[T_UNROLL];
-              uint32_t as_[T_UNROLL];
-#pragma unroll
-              for (int u = 0; u < T_UNROLL; ++u) {
-                  const uint32_t c = cc + 64u * u;
-                  aq[u] = make_uint2(0, 0); as_[u] = 0;
-                  if (c < lim) {
-                      const uint32_t sg = cmap[c];
-                      const int32_t m0 = (int32_t)(seg[G_M * T_SEGCAP + sg] & 0xFFFFu);
-                      const int32_t j0 = ((int32_t)(c + base - (seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
-                      const int64_t rb = (int64_t)seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
-                      aq[u] = *(const uint2 *)(rd.qual + rb);
-                      as_[u] = *(const uint32_t *)(rd.seq + (rb >> 1));
-                  }
-              }
-#pragma unroll
-              for (int u = 0; u < T_UNROLL; ++u) {
-                const uint32_t c = cc + 64u * u;
-                if (c >= lim) continue;
-                const uint32_t sg = cmap[c];
-                const uint32_t mm = seg[G_M * T_SEGCAP + sg];
-                const int32_t m0 = (int32_t)(mm & 0xFFFFu), m1 = (int32_t)(mm >> 16);
-                const int32_t j0 = ((int32_t)(c + base - (seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
-                const int32_t d0 = (int32_t)seg[G_R0 * T_SEGCAP + sg] + (j0 - m0) - win_base;   // window offset of base 0
-                const uint2 qw = aq[u];
-                uint32_t sw = as_[u];
-                // per-byte flags (bit 7): base inside [m0, m1) and quality >= min_quality
-                int32_t klo = m0 - j0, khi = m1 - j0;
-                klo = klo < 0 ? 0 : klo; khi = khi > 8 ? 8 : khi;
-                const uint64_t inm = (khi >= 8 ? ~0ull : ((1ull << (khi * 8)) - 1ull)) & ~((1ull << (klo * 8)) - 1ull);
-                uint32_t ok0, ok1;
-                if (mq <= 128) {
-                    const uint32_t mqb = (uint32_t)mq * 0x01010101u;
-                    ok0 = ((((qw.x & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.x) & 0x80808080u;
-                    ok1 = ((((qw.y & 0x7F7F7F7Fu) | 0x80808080u) - mqb) | qw.y) & 0x80808080u;
-                } else {
-                    ok0 = ok1 = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        ok0 |= (((qw.x >> (8 * b)) & 0xFFu) >= (uint32_t)mq ? 0x80u : 0u) << (8 * b);
-                        ok1 |= (((qw.y >> (8 * b)) & 0xFFu) >= (uint32_t)mq ? 0x80u : 0u) << (8 * b);
-                    }
-                }
-                ok0 &= (uint32_t)inm; ok1 &= (uint32_t)(inm >> 32);
-                // any counted base with a code outside A C G T N, or a chunk that leaves the LDS window: careful path
-                sw = ((sw & 0x0F0F0F0Fu) << 4) | ((sw >> 4) & 0x0F0F0F0Fu);   // base k at bits [4k, 4k+4)
-                uint32_t pc = sw - ((sw >> 1) & 0x55555555u);
-                pc = (pc & 0x33333333u) + ((pc >> 2) & 0x33333333u);         // per-nibble popcount
-                const uint32_t odd = (pc ^ 0x11111111u), four = (pc ^ 0x44444444u);
-                // nibble is fine when popcount == 1 or == 4; flag nibbles where neither holds
-                const uint32_t z1 = ((odd | (odd >> 1) | (odd >> 2) | (odd >> 3)) & 0x11111111u);   // 1 where pc != 1
-                const uint32_t z4 = ((four | (four >> 1) | (four >> 2) | (four >> 3)) & 0x11111111u); // 1 where pc != 4
-                const uint32_t nm = (khi >= 8 ? 0xFFFFFFFFu : ((1u << (khi * 4)) - 1u)) & ~((1u << (klo * 4)) - 1u);
-                const bool safe = (z1 & z4 & nm) == 0u && (uint32_t)d0 <= tc.wlim - 8u && tc.wlim >= 8u;
-                if (safe) {
-                    // rotate the 8 bases by `rot` so that lanes serviced together spread over the banks
-                    const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
-                    const uint32_t oa = (rot & 4u) ? ok1 : ok0, ob = (rot & 4u) ? ok0 : ok1;
-                    const uint32_t sh = (rot & 3u) * 8u;
-                    const uint32_t k0 = __builtin_amdgcn_alignbit(ob, oa, sh), k1 = __builtin_amdgcn_alignbit(oa, ob, sh);
-                    const uint32_t sr = __builtin_amdgcn_alignbit(sw, sw, rot * 4u);
-                    lds_u8 *const wbase = (lds_u8 *)win + (uint32_t)d0 * 4u;
-                    uint32_t plane[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {    // all eight table reads first: they cannot move past the atomics
-                        const uint32_t code4 = b == 0 ? (sr << 2) & 0x3Cu : (sr >> (4 * b - 2)) & 0x3Cu;
-                        plane[b] = *(lds_u32 *)((lds_u8 *)lut + code4);
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t val = ((b < 4 ? k0 : k1) >> ((b & 3) * 8 + 7)) & 1u;
-                        const uint32_t bb4 = ((rot + (uint32_t)b) & 7u) * 4u;
-                        lds_add((lds_u32 *)(wbase + plane[b] + bb4), val);
-                    }
-                } else {
-                    bool bad = false;
-#pragma unroll 1
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t okb = ((b < 4 ? ok0 : ok1) >> ((b & 3) * 8 + 7)) & 1u;
-                        if (!okb) continue;
-                        const uint32_t col = col_of_code((sw >> (4 * b)) & 15u);
-                        const int32_t rp = win_base + d0 + b;
-                        if (col > 4u || (uint32_t)rp >= tc.G) bad = true;
-                        else tile_add(tc, rp, col);
-                    }
-                    if (bad) st[S_ERR * TILE + (seg[G_RC * T_SEGCAP + sg] & 0xFFu)] = 1u;
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one chunk at a time: keeps the live set small
-              }
-            }
+            p4_round(env, lane, lim, base);
         }
         wave_sync();
         AMP_STAMP(3);

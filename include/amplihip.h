@@ -119,7 +119,9 @@ typedef struct amp_trim_out {
 } amp_trim_out;
 
 /* Same batch with every pointer in DEVICE memory and 32-bit offsets:
- * cig_off32[i] = cig_off[i], seq_off8[i] = seq_off[i] / 8. */
+ * cig_off32[i] = cig_off[i], seq_off8[i] = seq_off[i] / 8.  seq and qual must be 8-byte aligned
+ * and have 16 bytes of readable slack after the last read (the kernels use 8- and 16-byte
+ * vector loads that may start in a read's last 8 bytes). */
 typedef struct amp_dev_reads {
     int64_t n_reads;
     const int32_t *pos;
