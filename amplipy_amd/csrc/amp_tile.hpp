@@ -64,6 +64,7 @@ struct WaveLds {
 struct BlockLds {
     uint32_t win[AMP_NSYM * T_W];
     uint32_t lut[16];                 // BAM base code -> byte offset of its count plane
+    uint32_t dcount;                  // entries of this block's deferred-list segment
     WaveLds wv[T_WAVES];
 };
 
@@ -457,7 +458,7 @@ __device__ __forceinline__ void p4_round(const ChunkEnv &E, int lane, uint32_t l
 template <bool STAMPS>
 __global__ void __launch_bounds__(T_WAVES * 64)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
-       int tiles_per_block, uint32_t phases) {
+       uint32_t *dcnt, int tiles_per_block, uint32_t phases) {
     __shared__ BlockLds L;
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -465,11 +466,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_block;
     const int64_t tile_end = tile_begin + tiles_per_block < n_tiles ? tile_begin + tiles_per_block : n_tiles;
-    if (tile_begin >= tile_end) return;
+    if (tile_begin >= tile_end) { if (threadIdx.x == 0) dcnt[blockIdx.x] = 0; return; }
 
     lds_u32 *const win = (lds_u32 *)L.win;
     lds_u32 *const lut = (lds_u32 *)L.lut;
     for (int i = tid; i < AMP_NSYM * T_W; i += T_WAVES * 64) win[i] = 0;
+    if (tid == 0) L.dcount = 0;
     if (tid < 16) { uint32_t c = col_of_code((uint32_t)tid); lut[tid] = c <= 4u ? c * (uint32_t)(T_W * 4) : 0u; }
     int32_t win_base = NO_WINDOW;
     lds_u32 *const st = (lds_u32 *)L.wv[wave].st;
@@ -713,12 +715,14 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 if (status) ++n_err;
                 if (out.status) out.status[i] = (uint8_t)status;
             }
+            // A single hot counter in global memory would serialise the whole chip (one returning atomic
+            // per tile); every block appends to its OWN segment of the list through an LDS counter.
             const unsigned long long m = __ballot(has);
             if (m) {
-                unsigned long long dbase = 0;
-                if (lane == 0) dbase = atomicAdd(&ctr[3], (unsigned long long)__popcll(m));
+                uint32_t dbase = 0;
+                if (lane == 0) dbase = __hip_atomic_fetch_add((lds_u32 *)&L.dcount, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 dbase = __shfl(dbase, 0);
-                if (has) dlist[dbase + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+                if (has) dlist[(size_t)tile_begin * TILE + dbase + __popcll(m & ((1ull << lane) - 1ull))] = entry;
             }
         }
         AMP_STAMP(4);
@@ -737,20 +741,27 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
+    if (tid == 0) { dcnt[blockIdx.x] = L.dcount; if (L.dcount) atomicAdd(&ctr[3], (unsigned long long)L.dcount); }
     if (stamps && lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);
 }
 
-static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
-                              uint32_t *counts, const EventBuf &eb, uint32_t *dlist, int n_cu, uint32_t phases,
-                              hipStream_t stream) {
-    const int64_t n_tiles = (rd.n_reads + TILE - 1) / TILE;
-    if (n_tiles == 0) return 0;
-    int64_t max_blocks = (int64_t)n_cu;
-    int64_t tpb = (n_tiles + max_blocks - 1) / max_blocks;
+// Geometry shared by the tile kernel and the second pass: block b owns tiles [b*tpb, (b+1)*tpb).
+struct TileGrid { int64_t grid, tpb; };
+static inline TileGrid tile_grid(int64_t n_reads, int n_cu) {
+    const int64_t n_tiles = (n_reads + TILE - 1) / TILE;
+    int64_t tpb = (n_tiles + n_cu - 1) / n_cu;
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
-    int64_t grid = (n_tiles + tpb - 1) / tpb;
-    if (phases & 0x100u) k_tile<true><<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
-    else k_tile<false><<<(unsigned)grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, (int)tpb, phases);
+    if (tpb < T_WAVES) tpb = T_WAVES;
+    return TileGrid{(n_tiles + tpb - 1) / tpb, tpb};
+}
+
+static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
+                              uint32_t *counts, const EventBuf &eb, uint32_t *dlist, uint32_t *dcnt, int n_cu,
+                              uint32_t phases, hipStream_t stream) {
+    if (rd.n_reads == 0) return 0;
+    const TileGrid tg = tile_grid(rd.n_reads, n_cu);
+    if (phases & 0x100u) k_tile<true><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases);
+    else k_tile<false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases);
     return (int)hipGetLastError();
 }
 

@@ -207,11 +207,12 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
 // The list is dense, so the serial per-read code runs with every lane busy.
 __global__ void __launch_bounds__(256)
 k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist) {
-    const unsigned long long cnt = eb.ctr[3];
-    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < cnt;
-         k += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t e = dlist[k];
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
+    // block b of this launch finishes the list segment written by block b of the tile kernel
+    const uint32_t cnt = dcnt[blockIdx.x];
+    const uint32_t *seg = dlist + (size_t)blockIdx.x * (size_t)tiles_per_block * TILE;
+    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+        const uint32_t e = seg[k];
         const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
         bool status_only = (e & DEFER_STATUS_ONLY) != 0;
         if (e & DEFER_INDELS) {
@@ -559,10 +560,12 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
                o ? o->trim_flags : nullptr, o ? o->status : nullptr};
     // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3) * 4));
+    const TileGrid tg = tile_grid(n, c->n_cu);
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
-    uint32_t *dlist = scr + slots;
-    uint32_t *extra = dlist + n;
+    uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
+    uint32_t *dcnt = dlist + (size_t)tg.grid * (size_t)tg.tpb * TILE;  // entries used in each segment
+    uint32_t *extra = dcnt + tg.grid + 64;
     if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
     extra += n;
     if (!out.new_ncig) { out.new_ncig = extra; }
@@ -578,11 +581,11 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     } else {
         HIPCHK(c, hipMemsetAsync(&c->d_ctr[3], 0, sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, c->n_cu, c->phases, c->stream);
+        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_reads_deferred<<<(unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * 4), 256, 0, c->stream>>>(
-            P, *rd, read_base, out, scr, c->d_counts, eb, dlist);
+        k_reads_deferred<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
+                                                                   (long long)tg.tpb);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
