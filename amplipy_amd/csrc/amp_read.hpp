@@ -45,14 +45,17 @@ struct DevOut {
 
 // Where insertion events go: the event list (bounded by cap; the cursor keeps counting so the
 // host can detect a short reservation) and the per-position event tally used by calling.
+constexpr int EV_SHARDS = 8;     // event cursors: ctr[16 .. 16+EV_SHARDS)
 struct EventBuf {
-    amp_ins_event *ev;
-    unsigned long long *ctr;   // [0] events, [1] bound, [2] error reads, [3] deferred reads
+    amp_ins_event *ev;         // EV_SHARDS regions of `cap` events each
+    unsigned long long *ctr;   // [1] bound, [2] error reads, [3] deferred reads, [16+s] events of shard s
     uint32_t *ins_at;          // [ref_len]
-    long long cap;
+    long long cap;             // per shard
+    // One cursor per shard (block id modulo EV_SHARDS): a single hot counter serialises the chip.
     __device__ void record(int32_t pos, uint32_t read, int32_t lo, int32_t hi) const {
-        unsigned long long idx = atomicAdd(&ctr[0], 1ull);
-        if ((long long)idx < cap) ev[idx] = amp_ins_event{pos, read, lo, hi};
+        const unsigned s = blockIdx.x & (EV_SHARDS - 1);
+        unsigned long long idx = atomicAdd(&ctr[16 + s], 1ull);
+        if ((long long)idx < cap) ev[(size_t)s * (size_t)cap + idx] = amp_ins_event{pos, read, lo, hi};
         atomicAdd(&ins_at[pos], 1u);
     }
 };

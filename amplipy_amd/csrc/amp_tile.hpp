@@ -35,8 +35,8 @@
 namespace amp {
 
 constexpr int TILE = 64;          // reads per wave tile
-constexpr int T_WAVES = 16;       // waves per block (one block per CU)
-constexpr int T_W = 1024;         // reference positions covered by the LDS window
+constexpr int T_WAVES = 8;        // waves per block (two blocks per CU)
+constexpr int T_W = 512;          // reference positions covered by the LDS window
 constexpr int T_MAXOPS = 8;       // CIGAR ops per read held in LDS (input ops <= T_MAXOPS-3)
 constexpr int T_MAPCAP = T_MAXOPS * TILE * 4;   // chunk-map bytes = the spare CIGAR buffer
 constexpr int T_SEGCAP = 128;     // match-op segments per tile
@@ -456,7 +456,7 @@ __device__ __forceinline__ void p4_round(const ChunkEnv &E, int lane, uint32_t l
 
 // ---------------------------------------------------------------------------------------
 template <bool STAMPS>
-__global__ void __launch_bounds__(T_WAVES * 64)
+__global__ void __launch_bounds__(T_WAVES * 64, 4)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
        uint32_t *dcnt, int tiles_per_block, uint32_t phases) {
     __shared__ BlockLds L;
@@ -485,7 +485,9 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);          // sums of W bytes never reach 256*W
     unsigned long long n_err = 0;
     constexpr bool stamps = STAMPS;
+    const unsigned long long t_kernel0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t bs_rebase = 0, bs_c2 = 0, bs_c4 = 0;
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
         // ---- window management (uniform over the block) ------------------------------------
@@ -503,6 +505,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 }
             }
             win_base = first_pos & ~31;
+            ++bs_rebase;
             __syncthreads();
         }
         tc.win_base = win_base;
@@ -573,6 +576,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         st[S_CB2 * TILE + lane] = cb2;
 
         AMP_STAMP(0);
+        bs_c2 += total2;
         // =================================== P2: lane = chunk ===================================
         for (uint32_t base = 0; base < total2; base += T_MAPCAP) {
             wave_sync();
@@ -642,13 +646,13 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (!have_qual) regular = false;
             int e1 = 0, e2 = 0;
             if (regular) { (void)query_alignment_start(cur, ts.n, lseq, e1); (void)query_alignment_end(cur, ts.n, lseq, e2); }
-            if (!regular || e1 || e2) { defer_full = true; nseg = 0; if (stamps) atomicAdd(&ctr[6], 1ull); }
+            if (!regular || e1 || e2) { defer_full = true; nseg = 0; }
             else counted = true;
         }
         // segments: one per match op, allotted by a wave scan; a read that does not fit is deferred
         uint32_t total_seg;
         uint32_t sb = wave_excl_scan((uint32_t)nseg, lane, total_seg);
-        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; if (stamps) atomicAdd(&ctr[7], 1ull); }
+        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }
         uint32_t nch4 = 0;
         if (counted) {
             int32_t q = 0, r = ts.pos;
@@ -679,6 +683,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
 
         AMP_STAMP(2);
+        bs_c4 += total4;
         // =================================== P4: lane = chunk ===================================
         for (uint32_t base = 0; base < total4; base += T_MAPCAP) {
             wave_sync();
@@ -730,7 +735,9 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     }
 
     // ---- final flush ------------------------------------------------------------------------
+    const unsigned long long t_loopend = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     __syncthreads();
+    const unsigned long long t_barrier = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (win_base != NO_WINDOW) {
         for (int i = tid; i < AMP_NSYM * T_W; i += T_WAVES * 64) {
             uint32_t v = win[i];
@@ -742,14 +749,29 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
     if (tid == 0) { dcnt[blockIdx.x] = L.dcount; if (L.dcount) atomicAdd(&ctr[3], (unsigned long long)L.dcount); }
-    if (stamps && lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);
+    if (stamps && lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);
+        atomicAdd(&ctr[6], t_loopend - t_kernel0);      // time a wave spends in its tile loop
+        atomicAdd(&ctr[7], t_barrier - t_loopend);      // ... waiting for the slowest wave of its block
+        atomicAdd(&ctr[15], 1ull);
+        if (tid == 0) {
+            const unsigned long long dur = __builtin_amdgcn_s_memtime() - t_kernel0;
+            atomicMax(&ctr[14], (dur << 16) | (unsigned long long)(blockIdx.x & 0xFFFF));            // slowest block and its id
+            atomicMax(&ctr[5], ((0xFFFFFFFFFFFFull - dur) << 16) | (unsigned long long)(blockIdx.x & 0xFFFF));   // fastest block
+            atomicAdd(&ctr[4], dur);
+            dcnt[gridDim.x + 64 + blockIdx.x * 4 + 0] = (uint32_t)dur; dcnt[gridDim.x + 64 + blockIdx.x * 4 + 1] = bs_rebase;
+        }
+        if (lane == 0) { atomicAdd(&dcnt[gridDim.x + 64 + blockIdx.x * 4 + 2], bs_c2); atomicAdd(&dcnt[gridDim.x + 64 + blockIdx.x * 4 + 3], bs_c4); }
+    }
 }
 
 // Geometry shared by the tile kernel and the second pass: block b owns tiles [b*tpb, (b+1)*tpb).
 struct TileGrid { int64_t grid, tpb; };
 static inline TileGrid tile_grid(int64_t n_reads, int n_cu) {
     const int64_t n_tiles = (n_reads + TILE - 1) / TILE;
-    int64_t tpb = (n_tiles + n_cu - 1) / n_cu;
+    // eight blocks per CU: two are resident, the rest are handed out as CUs free up,
+    // which evens out the (measured) speed differences between XCDs
+    int64_t tpb = (n_tiles + 8 * (int64_t)n_cu - 1) / (8 * (int64_t)n_cu);
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
     if (tpb < T_WAVES) tpb = T_WAVES;
     return TileGrid{(n_tiles + tpb - 1) / tpb, tpb};

@@ -58,8 +58,8 @@ struct amp_ctx {
     bool have_primers = false;
     int32_t min_quality = 20, window = 4, do_trim = 1, do_count = 1;
     // insertion events
-    DBuf events;                  // amp_ins_event[ev_cap]
-    int64_t ev_cap = 0;
+    DBuf events;                  // amp_ins_event[EV_SHARDS][ev_cap]
+    int64_t ev_cap = 0;           // per shard
     bool ev_reserved = false;     // caller sized the buffer: skip the bound pre-pass
     unsigned long long *d_ctr = nullptr;  // [0] events recorded, [1] event bound, [2] error reads, [3] deferred reads
     uint32_t *d_ins_at = nullptr;         // [ref_len] insertion events per reference position
@@ -74,9 +74,12 @@ struct amp_ctx {
     bool timed = false;
     int n_cu = 256;
     int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = tile kernel
+    uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
     uint32_t phases = 0xFFu;       // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
     char err[320] = {0};
 };
+
+static hipError_t grow_events(amp_ctx *c, int64_t ncap);
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -87,6 +90,24 @@ struct amp_ctx {
             return e__ == hipErrorOutOfMemory ? AMP_ENOMEM : AMP_EHIP;                             \
         }                                                                                          \
     } while (0)
+
+static hipError_t grow_events(amp_ctx *c, int64_t ncap) {   // re-lays the shard regions out for a larger capacity
+    if (ncap <= c->ev_cap) return hipSuccess;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, (size_t)EV_SHARDS * (size_t)ncap * sizeof(amp_ins_event));
+    if (e != hipSuccess) return e;
+    if (c->events.p && c->ev_cap) {
+        for (int s = 0; s < EV_SHARDS && e == hipSuccess; ++s)
+            e = hipMemcpyAsync((amp_ins_event *)np + (size_t)s * ncap, c->events.as<amp_ins_event>() + (size_t)s * c->ev_cap,
+                               (size_t)c->ev_cap * sizeof(amp_ins_event), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(np); return e; }
+    }
+    c->events.release();
+    c->events.p = np; c->events.cap = (size_t)EV_SHARDS * (size_t)ncap * sizeof(amp_ins_event);
+    c->ev_cap = ncap;
+    return hipSuccess;
+}
 
 struct Guard {  // make the ctx's device current for the duration of a call
     int prev = -1;
@@ -434,10 +455,10 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     c->d_ins_at = c->d_counts + (size_t)ref_len * AMP_NSYM;
     if (hipMalloc((void **)&c->d_min_start, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_max_end, (size_t)ref_len * 4) != hipSuccess) return fail(AMP_ENOMEM);
-    if (hipMalloc((void **)&c->d_ctr, 16 * sizeof(unsigned long long)) != hipSuccess) return fail(AMP_ENOMEM);
+    if (hipMalloc((void **)&c->d_ctr, 32 * sizeof(unsigned long long)) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMalloc((void **)&c->d_ref, (size_t)ref_len) != hipSuccess) return fail(AMP_ENOMEM);
     if (hipMemsetAsync(c->d_counts, 0, cb, c->stream) != hipSuccess) return fail(AMP_EHIP);
-    if (hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
+    if (hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
@@ -519,8 +540,7 @@ int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kern
 int amp_reserve_events(amp_ctx *c, int64_t cap) {
     if (!c || cap < 0) return AMP_EINVAL;
     Guard g(c);
-    HIPCHK(c, c->events.ensure((size_t)cap * sizeof(amp_ins_event), true, c->stream));
-    c->ev_cap = std::max(c->ev_cap, cap);
+    HIPCHK(c, grow_events(c, cap));
     c->ev_reserved = true;
     return AMP_OK;
 }
@@ -540,18 +560,16 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     if (n == 0) return AMP_OK;
     // event capacity
     if (c->do_count && !c->ev_reserved) {
-        unsigned long long h[2] = {0, 0};
+        unsigned long long h[32];
         HIPCHK(c, hipMemsetAsync(&c->d_ctr[1], 0, sizeof(unsigned long long), c->stream));
         k_event_bound<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(n, rd->cig_off32, rd->cig, c->d_ctr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        int64_t need = (int64_t)(h[0] + h[1]);
-        if (need > c->ev_cap) {
-            int64_t ncap = std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2);
-            HIPCHK(c, c->events.ensure((size_t)ncap * sizeof(amp_ins_event), true, c->stream));
-            c->ev_cap = ncap;
-        }
+        unsigned long long mx = 0;
+        for (int s = 0; s < EV_SHARDS; ++s) mx = std::max(mx, h[16 + s]);
+        const int64_t need = (int64_t)(mx + h[1]);          // any shard may receive every new event
+        if (need > c->ev_cap) HIPCHK(c, grow_events(c, std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2)));
     }
     KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end};
     if (n > 0x7FFFFFFFll) return AMP_EINVAL;
@@ -561,11 +579,13 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
     const TileGrid tg = tile_grid(n, c->n_cu);
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid * 5 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
     uint32_t *dcnt = dlist + (size_t)tg.grid * (size_t)tg.tpb * TILE;  // entries used in each segment
-    uint32_t *extra = dcnt + tg.grid + 64;
+    uint32_t *extra = dcnt + tg.grid * 5 + 64;
+    c->dbg_dcnt = dcnt; c->dbg_grid = (int)tg.grid;
+    if (c->phases & 0x100u) HIPCHK(c, hipMemsetAsync(dcnt, 0, ((size_t)tg.grid * 5 + 64) * 4, c->stream));
     if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
     extra += n;
     if (!out.new_ncig) { out.new_ncig = extra; }
@@ -687,19 +707,34 @@ void *amp_counts_device_ptr(amp_ctx *c) { return c ? c->d_counts : nullptr; }
 int amp_get_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap) {
     if (!c || !n) return AMP_EINVAL;
     Guard g(c);
-    unsigned long long h = 0;
-    HIPCHK(c, hipMemcpyAsync(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[EV_SHARDS];
+    HIPCHK(c, hipMemcpyAsync(h, &c->d_ctr[16], sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *n = (int64_t)h;
-    if ((int64_t)h > c->ev_cap) return AMP_EOVERFLOW;  // reserved buffer was too small: events were dropped
+    int64_t total = 0;
+    bool dropped = false;
+    for (int s = 0; s < EV_SHARDS; ++s) { total += (int64_t)h[s]; if ((int64_t)h[s] > c->ev_cap) dropped = true; }
+    *n = total;
+    if (dropped) return AMP_EOVERFLOW;   // a reserved buffer was too small: events were dropped
     if (buf) {
-        int64_t m = std::min<int64_t>((int64_t)h, cap);
-        if (m > 0) {
-            HIPCHK(c, hipMemcpyAsync(buf, c->events.p, (size_t)m * sizeof(amp_ins_event), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (total > cap) return AMP_EOVERFLOW;
+        int64_t o = 0;
+        for (int s = 0; s < EV_SHARDS; ++s) {
+            if (h[s]) HIPCHK(c, hipMemcpyAsync(buf + o, c->events.as<amp_ins_event>() + (size_t)s * c->ev_cap,
+                                               (size_t)h[s] * sizeof(amp_ins_event), hipMemcpyDeviceToHost, c->stream));
+            o += (int64_t)h[s];
         }
-        if ((int64_t)h > cap) return AMP_EOVERFLOW;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return AMP_OK;
+}
+
+int amp_debug_blocks(amp_ctx *c, uint32_t *out, int cap_blocks, int *n_blocks) {   // [block][dur, rebases, p2 chunks, p4 chunks]
+    if (!c || !out || !n_blocks || !c->dbg_dcnt) return AMP_EINVAL;
+    Guard g(c);
+    int nb = c->dbg_grid < cap_blocks ? c->dbg_grid : cap_blocks;
+    HIPCHK(c, hipMemcpyAsync(out, c->dbg_dcnt + c->dbg_grid + 64, (size_t)nb * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_blocks = nb;
     return AMP_OK;
 }
 
@@ -725,7 +760,7 @@ int amp_reset(amp_ctx *c) {
     if (!c) return AMP_EINVAL;
     Guard g(c);
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_DEV_COLS * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream));
     return AMP_OK;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks",
 ]
 
 
@@ -170,6 +170,11 @@ class Engine:
             self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)),
                       "amp_get_ins_events")
         return ev
+
+    def debug_blocks(self):
+        out = np.zeros((4096, 4), np.uint32); nb = C.c_int(0)
+        self._chk(self.L.amp_debug_blocks(self.h, C.c_void_p(abi.ptr(out)), C.c_int(4096), C.byref(nb)), "amp_debug_blocks")
+        return out[:nb.value]
 
     def debug_counters(self):
         out = np.zeros(16, np.uint64)

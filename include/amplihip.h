@@ -200,6 +200,9 @@ int amp_error_reads(amp_ctx *ctx, int64_t *n);
 /* Development aid: the 16 raw device counters ([0] events, [1] event bound, [2] error reads,
  * [3] deferred reads, [8..13] per-phase cycle sums when AMPLIHIP_PHASES has bit 0x100). */
 int amp_debug_counters(amp_ctx *ctx, uint64_t *out16);
+/* Development aid (AMPLIHIP_PHASES bit 0x100): per tile-kernel block {cycles, window rebases,
+ * quality-scan chunks, counting chunks} of the last launch. */
+int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks);
 /* Pre-size the insertion-event buffer.  Without it every amp_process_batch* call first runs
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
  * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short. */
