@@ -208,20 +208,35 @@ k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32
     process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, false);
 }
 
+// one CIGAR column in LDS for the second pass (stride = block size)
+struct LdsCig256 {
+    lds_u32 *p;
+    __device__ __forceinline__ uint32_t get(int i) const { return p[i * 256]; }
+    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * 256] = v; }
+};
+
 // Deletions / reference skips and insertion events of a read whose match bases the tile kernel
-// already counted: the skip-ahead walk over the FINAL CIGAR the tile kernel wrote out.
+// already counted: the skip-ahead walk over the FINAL CIGAR the tile kernel wrote out (staged in an
+// LDS column first: the walk re-reads ops many times).
 __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
-                                   uint32_t *counts, const EventBuf &eb) {
+                                   uint32_t *counts, const EventBuf &eb, lds_u32 *col) {
     const size_t slot = (size_t)rd.cig_off32[i] + 3 * (size_t)i;
-    const CigBuf<1> cig{out.new_cig + slot};
     const int n = (int)out.new_ncig[i];
     const int32_t lseq = (int32_t)rd.lseq[i];
+    const int32_t pos = out.new_pos[i];
     const uint8_t *qual = rd.qual + (int64_t)rd.seq_off8[i] * 8;
-    int e1 = 0, e2 = 0;
-    const int32_t qs = query_alignment_start(cig, n, lseq, e1), qe = query_alignment_end(cig, n, lseq, e2);
     DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
     struct Q { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } } qf{qual};
-    return count_regular_skip(P, cig, n, out.new_pos[i], lseq, qs, qe, qf, sink);
+    int e1 = 0, e2 = 0;
+    if (n <= T_MAXOPS) {
+        const LdsCig256 cig{col};
+        for (int k = 0; k < n; ++k) cig.set(k, out.new_cig[slot + k]);
+        const int32_t qs = query_alignment_start(cig, n, lseq, e1), qe = query_alignment_end(cig, n, lseq, e2);
+        return count_regular_skip(P, cig, n, pos, lseq, qs, qe, qf, sink);
+    }
+    const CigBuf<1> cig{out.new_cig + slot};
+    const int32_t qs = query_alignment_start(cig, n, lseq, e1), qe = query_alignment_end(cig, n, lseq, e2);
+    return count_regular_skip(P, cig, n, pos, lseq, qs, qe, qf, sink);
 }
 
 // Second pass of variant 2: the reads the tile kernel put on its deferred list, one per lane.
@@ -229,6 +244,7 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
 __global__ void __launch_bounds__(256)
 k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
                  EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
+    __shared__ uint32_t s_cig[T_MAXOPS * 256];
     // block b of this launch finishes the list segment written by block b of the tile kernel
     const uint32_t cnt = dcnt[blockIdx.x];
     const uint32_t *seg = dlist + (size_t)blockIdx.x * (size_t)tiles_per_block * TILE;
@@ -237,7 +253,7 @@ k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
         const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
         bool status_only = (e & DEFER_STATUS_ONLY) != 0;
         if (e & DEFER_INDELS) {
-            if (process_read_indels(P, rd, i, read_base, out, counts, eb)) status_only = true;   // exact status below
+            if (process_read_indels(P, rd, i, read_base, out, counts, eb, (lds_u32 *)s_cig + threadIdx.x)) status_only = true;   // exact status below
             else if (!status_only) continue;
         }
         process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, status_only);
@@ -307,34 +323,44 @@ __global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__re
 
 // Packs the outcome of k_call for the host: consensus column per position, the variant records in
 // ascending position (insertion-relevant positions excluded: the host finishes those), and the list
-// of insertion-relevant positions.  One block; each thread owns a contiguous run of positions.
-__global__ void __launch_bounds__(1024)
-k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__ counts, int32_t ref_len,
-               int8_t *__restrict__ cons, amp_var_rec *__restrict__ vars, int32_t *__restrict__ rel, unsigned long long *n_out) {
-    __shared__ uint32_t sv[1024], sr[1024];
-    const int tid = threadIdx.x;
-    const int32_t per = (ref_len + 1023) / 1024;
-    const int32_t p0 = tid * per, p1 = p0 + per < ref_len ? p0 + per : ref_len;
-    uint32_t nv = 0, nr = 0;
-    for (int32_t p = p0; p < p1; ++p) {
-        const uint8_t f = pc[p].flags;
-        if (f & AMP_CALL_INS_RELEVANT) ++nr; else if (f & AMP_CALL_VARIANT) ++nv;
-    }
-    sv[tid] = nv; sr[tid] = nr;
+// of insertion-relevant positions.  Pass 1 counts per 256-position block, pass 2 places each
+// block's records behind the totals of the blocks before it.
+__global__ void __launch_bounds__(256)
+k_call_count(const amp_pos_call *__restrict__ pc, int32_t ref_len, uint2 *__restrict__ blk) {
+    __shared__ uint32_t sv[4], sr[4];
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t f = p < ref_len ? pc[p].flags : 0;
+    const bool isr = (f & AMP_CALL_INS_RELEVANT) != 0, isv = !isr && (f & AMP_CALL_VARIANT);
+    const unsigned long long bv = __ballot(isv), br = __ballot(isr);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = (uint32_t)__popcll(bv); sr[threadIdx.x >> 6] = (uint32_t)__popcll(br); }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint32_t a = tid >= o ? sv[tid - o] : 0u, b = tid >= o ? sr[tid - o] : 0u;
-        __syncthreads();
-        sv[tid] += a; sr[tid] += b;
-        __syncthreads();
-    }
-    uint32_t ov = sv[tid] - nv, orl = sr[tid] - nr;
-    if (tid == 1023) { n_out[0] = sv[1023]; n_out[1] = sr[1023]; }
-    for (int32_t p = p0; p < p1; ++p) {
-        const amp_pos_call c = pc[p];
-        cons[p] = c.consensus_sym;
-        if (c.flags & AMP_CALL_INS_RELEVANT) { rel[orl++] = p; continue; }
-        if (!(c.flags & AMP_CALL_VARIANT)) continue;
+    if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], sr[0] + sr[1] + sr[2] + sr[3]);
+}
+
+__global__ void __launch_bounds__(256)
+k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__ counts, int32_t ref_len, const uint2 *__restrict__ blk,
+               int8_t *__restrict__ cons, amp_var_rec *__restrict__ vars, int32_t *__restrict__ rel, unsigned long long *n_out) {
+    __shared__ uint32_t s_pv[4], s_pr[4], s_wv[4], s_wr[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // totals of the blocks before this one
+    uint32_t pv = 0, prl = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) { const uint2 c = blk[b]; pv += c.x; prl += c.y; }
+    for (int o = 32; o > 0; o >>= 1) { pv += __shfl_down(pv, o); prl += __shfl_down(prl, o); }
+    if (lane == 0) { s_pv[wave] = pv; s_pr[wave] = prl; }
+    const int32_t p = blockIdx.x * 256 + tid;
+    amp_pos_call c;
+    c.flags = 0; c.consensus_sym = -1; c.alt_mask = 0; c.order = 0; c.total_depth = 0; c.ref_count = 0; c.pad = 0;
+    if (p < ref_len) { c = pc[p]; cons[p] = c.consensus_sym; }
+    const bool isr = (c.flags & AMP_CALL_INS_RELEVANT) != 0, isv = !isr && (c.flags & AMP_CALL_VARIANT);
+    const unsigned long long bv = __ballot(isv), br = __ballot(isr);
+    if (lane == 0) { s_wv[wave] = (uint32_t)__popcll(bv); s_wr[wave] = (uint32_t)__popcll(br); }
+    __syncthreads();
+    uint32_t ov = s_pv[0] + s_pv[1] + s_pv[2] + s_pv[3], orl = s_pr[0] + s_pr[1] + s_pr[2] + s_pr[3];
+    for (int w = 0; w < wave; ++w) { ov += s_wv[w]; orl += s_wr[w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    ov += (uint32_t)__popcll(bv & below); orl += (uint32_t)__popcll(br & below);
+    if (isr) rel[orl] = p;
+    if (isv) {
         amp_var_rec v;
         v.pos = p; v.total_depth = c.total_depth; v.ref_count = c.ref_count;
         v.gt_has_ref = (c.flags & AMP_CALL_GT_HAS_REF) ? 1 : 0;
@@ -347,7 +373,11 @@ k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__
             }
         }
         v.n_alt = na;
-        vars[ov++] = v;
+        vars[ov] = v;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) {   // last thread of the last block knows both totals
+        n_out[0] = ov + (isv ? 1u : 0u);
+        n_out[1] = orl + (isr ? 1u : 0u);
     }
 }
 
@@ -829,14 +859,18 @@ int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, a
     const size_t off_cons = (size_t)G * sizeof(amp_pos_call);
     const size_t off_vars = (off_cons + (size_t)G + 63) & ~(size_t)63;
     const size_t off_rel = off_vars + (size_t)G * sizeof(amp_var_rec);
-    HIPCHK(c, c->call_buf.ensure(off_rel + (size_t)G * 4));
+    const size_t off_blk = off_rel + (size_t)G * 4;
+    const unsigned nblk = (unsigned)((G + 255) / 256);
+    HIPCHK(c, c->call_buf.ensure(off_blk + (size_t)nblk * sizeof(uint2) + 64));
     uint8_t *base = c->call_buf.as<uint8_t>();
     amp_pos_call *d_pc = (amp_pos_call *)base;
     HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 3 * sizeof(unsigned long long), c->stream));
     k_call<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, &c->d_ctr[4]);
     HIPCHK(c, hipGetLastError());
-    k_call_compact<<<1, 1024, 0, c->stream>>>(d_pc, c->d_counts, G, (int8_t *)(base + off_cons), (amp_var_rec *)(base + off_vars),
-                                              (int32_t *)(base + off_rel), &c->d_ctr[5]);
+    k_call_count<<<nblk, 256, 0, c->stream>>>(d_pc, G, (uint2 *)(base + off_blk));
+    HIPCHK(c, hipGetLastError());
+    k_call_compact<<<nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + off_blk), (int8_t *)(base + off_cons),
+                                                (amp_var_rec *)(base + off_vars), (int32_t *)(base + off_rel), &c->d_ctr[5]);
     HIPCHK(c, hipGetLastError());
     unsigned long long nn[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(nn, &c->d_ctr[5], sizeof(nn), hipMemcpyDeviceToHost, c->stream));
