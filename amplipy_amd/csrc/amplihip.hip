@@ -70,6 +70,8 @@ struct amp_ctx {
     DBuf o_pos, o_ncig, o_cig, o_reflen, o_flags, o_status;
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
+    void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
+    int64_t last_nv = 0, last_nr = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timed = false;
     int n_cu = 256;
@@ -274,9 +276,11 @@ __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
 // AMP_CALL_INS_RELEVANT and finished by the host from the event list.
 __global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ins_at,
                        const uint8_t *__restrict__ ref, int32_t ref_len, amp_call_params pr, amp_pos_call *__restrict__ out,
-                       unsigned long long *n_relevant) {
+                       unsigned long long *n_relevant, uint2 *__restrict__ blk) {
+    __shared__ uint32_t sv[4], sr[4];
     int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= ref_len) return;
+    const bool live = p < ref_len;
+    if (!live) p = ref_len - 1;            // keep the whole block alive for the block-level counts
     const int desc[6] = {3, 4, 2, 1, 0, 5};            // T N G C A -
     const char sym_of[6] = {'A', 'C', 'G', 'T', 'N', '-'};
     uint32_t c[6], idx[6];
@@ -317,26 +321,21 @@ __global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__re
         if ((int64_t)total >= (int64_t)pr.min_depth_variants && n_alt) o.flags |= AMP_CALL_VARIANT;
         if ((int64_t)rc >= (int64_t)pr.min_depth_variants && rf >= pr.min_freq_variants) o.flags |= AMP_CALL_GT_HAS_REF;
     }
-    if (relevant) { o.flags |= AMP_CALL_INS_RELEVANT; atomicAdd(n_relevant, 1ull); }
-    out[p] = o;
+    if (relevant) { o.flags |= AMP_CALL_INS_RELEVANT; if (n_relevant && live) atomicAdd(n_relevant, 1ull); }
+    if (live) out[p] = o;
+    if (blk) {   // records per 256-position block, for k_call_compact
+        const bool isr = live && relevant, isv = live && !relevant && (o.flags & AMP_CALL_VARIANT);
+        const unsigned long long bv = __ballot(isv), br = __ballot(isr);
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = (uint32_t)__popcll(bv); sr[threadIdx.x >> 6] = (uint32_t)__popcll(br); }
+        __syncthreads();
+        if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], sr[0] + sr[1] + sr[2] + sr[3]);
+    }
 }
 
 // Packs the outcome of k_call for the host: consensus column per position, the variant records in
 // ascending position (insertion-relevant positions excluded: the host finishes those), and the list
-// of insertion-relevant positions.  Pass 1 counts per 256-position block, pass 2 places each
-// block's records behind the totals of the blocks before it.
-__global__ void __launch_bounds__(256)
-k_call_count(const amp_pos_call *__restrict__ pc, int32_t ref_len, uint2 *__restrict__ blk) {
-    __shared__ uint32_t sv[4], sr[4];
-    const int32_t p = blockIdx.x * 256 + threadIdx.x;
-    const uint8_t f = p < ref_len ? pc[p].flags : 0;
-    const bool isr = (f & AMP_CALL_INS_RELEVANT) != 0, isv = !isr && (f & AMP_CALL_VARIANT);
-    const unsigned long long bv = __ballot(isv), br = __ballot(isr);
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = (uint32_t)__popcll(bv); sr[threadIdx.x >> 6] = (uint32_t)__popcll(br); }
-    __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], sr[0] + sr[1] + sr[2] + sr[3]);
-}
-
+// of insertion-relevant positions.  k_call leaves per-256-position-block record counts; each block
+// here places its records behind the totals of the blocks before it.
 __global__ void __launch_bounds__(256)
 k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__ counts, int32_t ref_len, const uint2 *__restrict__ blk,
                int8_t *__restrict__ cons, amp_var_rec *__restrict__ vars, int32_t *__restrict__ rel, unsigned long long *n_out) {
@@ -508,6 +507,7 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->d_min_start) (void)hipFree(c->d_min_start);
     if (c->d_max_end) (void)hipFree(c->d_max_end);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_ref) (void)hipFree(c->d_ref);
     DBuf *bufs[] = {&c->events, &c->s_pos, &c->s_flag, &c->s_tlen, &c->s_lseq, &c->s_cigoff, &c->s_cig, &c->s_seqoff,
                     &c->s_seq, &c->s_qual, &c->o_pos, &c->o_ncig, &c->o_cig, &c->o_reflen, &c->o_flags, &c->o_status,
@@ -840,7 +840,7 @@ int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out,
     HIPCHK(c, c->call_buf.ensure((size_t)G * sizeof(amp_pos_call)));
     HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, sizeof(unsigned long long), c->stream));
     k_call<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr,
-                                                              c->call_buf.as<amp_pos_call>(), &c->d_ctr[4]);
+                                                              c->call_buf.as<amp_pos_call>(), &c->d_ctr[4], nullptr);
     HIPCHK(c, hipGetLastError());
     unsigned long long nr = 0;
     HIPCHK(c, hipMemcpyAsync(out, c->call_buf.p, (size_t)G * sizeof(amp_pos_call), hipMemcpyDeviceToHost, c->stream));
@@ -864,23 +864,46 @@ int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, a
     HIPCHK(c, c->call_buf.ensure(off_blk + (size_t)nblk * sizeof(uint2) + 64));
     uint8_t *base = c->call_buf.as<uint8_t>();
     amp_pos_call *d_pc = (amp_pos_call *)base;
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 3 * sizeof(unsigned long long), c->stream));
-    k_call<<<(unsigned)((G + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, &c->d_ctr[4]);
-    HIPCHK(c, hipGetLastError());
-    k_call_count<<<nblk, 256, 0, c->stream>>>(d_pc, G, (uint2 *)(base + off_blk));
+    k_call<<<nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + off_blk));
     HIPCHK(c, hipGetLastError());
     k_call_compact<<<nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + off_blk), (int8_t *)(base + off_cons),
                                                 (amp_var_rec *)(base + off_vars), (int32_t *)(base + off_rel), &c->d_ctr[5]);
     HIPCHK(c, hipGetLastError());
-    unsigned long long nn[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(nn, &c->d_ctr[5], sizeof(nn), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(consensus, base + off_cons, (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    // one pinned round trip: totals + consensus + as many records as the previous call produced
+    // (plus a margin); a second copy only when this call produced more
+    const size_t pin_need = 64 + (size_t)G + (size_t)G * sizeof(amp_var_rec) + (size_t)G * 4;
+    if (c->h_pin_cap < pin_need) {
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr; c->h_pin_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_pin, pin_need, hipHostMallocDefault));
+        c->h_pin_cap = pin_need;
+    }
+    uint8_t *hp = (uint8_t *)c->h_pin;
+    unsigned long long *h_nn = (unsigned long long *)hp;
+    int8_t *h_cons = (int8_t *)(hp + 64);
+    amp_var_rec *h_vars = (amp_var_rec *)(hp + 64 + (((size_t)G + 63) & ~(size_t)63));
+    int32_t *h_rel = (int32_t *)((uint8_t *)h_vars + (size_t)G * sizeof(amp_var_rec));
+    const int64_t guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
+    const int64_t guess_r = std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64);
+    HIPCHK(c, hipMemcpyAsync(h_nn, &c->d_ctr[5], 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_cons, base + off_cons, (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_vars, base + off_vars, (size_t)guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_rel, base + off_rel, (size_t)guess_r * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *n_vars = (int64_t)nn[0]; *n_relevant = (int64_t)nn[1];
-    if ((int64_t)nn[0] > vars_cap || (int64_t)nn[1] > relevant_cap) return AMP_EOVERFLOW;
-    if (nn[0] && vars) HIPCHK(c, hipMemcpyAsync(vars, base + off_vars, (size_t)nn[0] * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-    if (nn[1] && relevant) HIPCHK(c, hipMemcpyAsync(relevant, base + off_rel, (size_t)nn[1] * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t nv = (int64_t)h_nn[0], nr = (int64_t)h_nn[1];
+    *n_vars = nv; *n_relevant = nr;
+    c->last_nv = nv; c->last_nr = nr;
+    if (nv > vars_cap || nr > relevant_cap) return AMP_EOVERFLOW;
+    if (nv > guess_v || nr > guess_r) {
+        if (nv > guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + guess_v, base + off_vars + (size_t)guess_v * sizeof(amp_var_rec),
+                                                   (size_t)(nv - guess_v) * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+        if (nr > guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + guess_r, base + off_rel + (size_t)guess_r * 4, (size_t)(nr - guess_r) * 4,
+                                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    memcpy(consensus, h_cons, (size_t)G);
+    if (nv && vars) memcpy(vars, h_vars, (size_t)nv * sizeof(amp_var_rec));
+    if (nr && relevant) memcpy(relevant, h_rel, (size_t)nr * 4);
     return AMP_OK;
 }
 

@@ -207,16 +207,20 @@ class Engine:
         return out, int(nr.value)
 
     def call_compact(self, params):
-        """amp_call_compact -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R])."""
+        """amp_call_compact -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R]).  The arrays
+        are views of buffers owned by the engine, valid until the next call."""
         G = self.ref_len
         if not hasattr(self, "_cc"):
-            self._cc = (np.zeros(G, np.int8), np.zeros(G, abi.VAR_REC_DTYPE), np.zeros(G, np.int32))
-        cons, vars_, rel = self._cc
-        nv = C.c_int64(0); nr = C.c_int64(0)
-        self._chk(self.L.amp_call_compact(self.h, C.byref(params), C.c_void_p(abi.ptr(cons)), C.c_void_p(abi.ptr(vars_)),
-                                          C.c_int64(G), C.byref(nv), C.c_void_p(abi.ptr(rel)), C.c_int64(G), C.byref(nr)),
-                  "amp_call_compact")
-        return cons.copy(), vars_[:nv.value].copy(), rel[:nr.value].copy()
+            bufs = (np.zeros(G, np.int8), np.zeros(G, abi.VAR_REC_DTYPE), np.zeros(G, np.int32))
+            nv = C.c_int64(0); nr = C.c_int64(0)
+            args = (C.c_void_p(abi.ptr(bufs[0])), C.c_void_p(abi.ptr(bufs[1])), C.c_int64(G), C.byref(nv),
+                    C.c_void_p(abi.ptr(bufs[2])), C.c_int64(G), C.byref(nr))
+            self._cc = (bufs, nv, nr, args)
+        bufs, nv, nr, args = self._cc
+        rc = self.L.amp_call_compact(self.h, C.byref(params), *args)
+        if rc:
+            self._chk(rc, "amp_call_compact")
+        return bufs[0], bufs[1][:nv.value], bufs[2][:nr.value]
 
     def event_strings_device(self, dev_reads, events, read_base=0):
         """Strings of ``events`` (INS_EVENT_DTYPE) taken from a device-resident batch."""

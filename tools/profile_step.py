@@ -18,9 +18,16 @@ def tick(k, t0):
 for it in range(25):
     if it == 5: T.clear()
     t0 = time.perf_counter(); e.reset(); tick("reset", t0)
-    t0 = time.perf_counter(); e.process_device(rd, 0, None); tick("process", t0)
-    t0 = time.perf_counter(); pcs = e.call_positions(cp); tick("call_positions", t0)
-    t0 = time.perf_counter(); c = e.counts(); tick("counts_d2h", t0)
-    t0 = time.perf_counter(); res = calling.call(e, ref_seq, cp, None, positions=pcs); tick("calling.call(total incl counts)", t0)
+    t0 = time.perf_counter(); e.process_device(rd, 0, None); T["process_launch"] = T.get("process_launch", 0.0) + time.perf_counter() - t0; tick("process", t0)
+    t0 = time.perf_counter(); k = e.last_kernel_ms(); tick("last_kernel_ms", t0)
+    t0 = time.perf_counter(); res = calling.call(e, ref_seq, cp, None); tick("calling.call (compact)", t0)
     t0 = time.perf_counter(); s = res.consensus_string("N"); tick("consensus_string", t0)
+for k, v in T.items(): print("%-36s %.3f ms" % (k, v / 20 * 1e3))
+import ctypes as C
+G = e.ref_len
+T.clear()
+for it in range(20):
+    e.reset(); e.process_device(rd, 0, None); torch.cuda.synchronize()
+    t0 = time.perf_counter(); r = e.call_compact(cp); T["lib.call_compact"] = T.get("lib.call_compact", 0) + time.perf_counter() - t0
+    t0 = time.perf_counter(); res = calling.result_from_compact(ref_seq, cp, *r[:2]); T["result_from_compact"] = T.get("result_from_compact", 0) + time.perf_counter() - t0
 for k, v in T.items(): print("%-36s %.3f ms" % (k, v / 20 * 1e3))
