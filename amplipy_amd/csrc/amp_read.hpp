@@ -54,6 +54,9 @@ struct EventBuf {
     // One cursor per shard (block id modulo EV_SHARDS): a single hot counter serialises the chip.
     __device__ void record(int32_t pos, uint32_t read, int32_t lo, int32_t hi) const {
         const unsigned s = blockIdx.x & (EV_SHARDS - 1);
+#ifdef AMP_EXP_NO_EVENTS
+        return;
+#endif
         unsigned long long idx = atomicAdd(&ctr[16 + s], 1ull);
         if ((long long)idx < cap) ev[(size_t)s * (size_t)cap + idx] = amp_ins_event{pos, read, lo, hi};
         atomicAdd(&ins_at[pos], 1u);
@@ -415,9 +418,39 @@ struct PairIter {
 
 // update_base_counts (A:690-753) for one read as an exact sequential walk.  Sink provides
 //   void add(int32_t ref_pos, uint32_t col)   and   void event(int32_t ref_pos, int32_t from, int32_t to)
-template <class CB, class Sink>
+// Plain accessor of one read's qualities and 4-bit base codes.
+struct ReadBytes {
+    const uint8_t *seq; int64_t base_off; const uint8_t *q;
+    AMP_HD uint32_t qual(int32_t i) { return q[i]; }
+    AMP_HD uint32_t code(int32_t i) { return base_code(seq, base_off, i); }
+};
+
+// The same with an 8-base register cache: the walk visits query indices in ascending order, so one
+// 8-byte + one 4-byte load serve eight bases (reads start on 8-base boundaries).
+struct ReadBytesCached {
+    const uint8_t *seq; int64_t base_off; const uint8_t *q;
+    int32_t blk = -1;
+    uint32_t q0 = 0, q1 = 0, s = 0;
+    AMP_HD void fetch(int32_t i) {
+        blk = i >> 3;
+        const uint32_t *qp = (const uint32_t *)(q + (int64_t)blk * 8);
+        q0 = qp[0]; q1 = qp[1];
+        s = *(const uint32_t *)(seq + ((base_off + (int64_t)blk * 8) >> 1));
+    }
+    AMP_HD uint32_t qual(int32_t i) {
+        if ((i >> 3) != blk) fetch(i);
+        return (((i & 4) ? q1 : q0) >> ((i & 3) * 8)) & 0xFFu;
+    }
+    AMP_HD uint32_t code(int32_t i) {
+        if ((i >> 3) != blk) fetch(i);
+        const uint32_t byte = (s >> (((i & 7) >> 1) * 8)) & 0xFFu;
+        return (i & 1) ? (byte & 15u) : (byte >> 4);
+    }
+};
+
+template <class CB, class Sink, class RB>
 AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_start, int32_t lseq,
-                           const uint8_t *seq, int64_t base_off, const uint8_t *qual, bool have_qual, Sink &sink) {
+                           RB rb, bool have_qual, Sink &sink) {
     int err = 0;
     const int32_t qs = query_alignment_start(cig, n, lseq, err);                           // A:700
     if (err) return err;
@@ -442,7 +475,7 @@ AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_s
         }
         if (!have_qual) return AMP_RS_NO_QUAL;
         if (q >= lseq) return AMP_RS_INDEX_QUERY;
-        if ((int32_t)qual[q] < mq) continue;                                               // A:718
+        if ((int32_t)rb.qual(q) < mq) continue;                                            // A:718
         if (q < qs) continue;                                                              // A:722
         if (q >= qe) break;                                                                // A:726
         if (r < 0) {                                                                       // A:730-748
@@ -450,7 +483,7 @@ AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_s
             bool q_none = false;
             while (r < 0 && !q_none && q < qe) {
                 if (q >= lseq) return AMP_RS_INDEX_QUERY;
-                if ((int32_t)qual[q] < mq) break;
+                if ((int32_t)rb.qual(q) < mq) break;
                 if (!it.next(q, r)) return AMP_RS_INDEX_PAIRS;                             // A:734
                 if (q < 0) q_none = true;
             }
@@ -472,7 +505,7 @@ AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_s
             continue;
         }
         if ((uint32_t)r >= G) return AMP_RS_INDEX_REF;                                     // A:751-753
-        const uint32_t col = code_to_col(base_code(seq, base_off, q));
+        const uint32_t col = code_to_col(rb.code(q));
         if (col == 0xFFu) return AMP_RS_KEY_BASE;
         sink.add(r, col);
     }

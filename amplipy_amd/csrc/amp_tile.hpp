@@ -64,7 +64,8 @@ struct WaveLds {
 struct BlockLds {
     uint32_t win[AMP_NSYM * T_W];
     uint32_t lut[16];                 // BAM base code -> byte offset of its count plane
-    uint32_t dcount;                  // entries of this block's deferred-list segment
+    uint32_t dcount;                  // light entries (indels only) of this block's deferred-list segment, from its front
+    uint32_t dcount2;                 // heavy entries (whole read / exact status), from its back
     WaveLds wv[T_WAVES];
 };
 
@@ -471,7 +472,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const win = (lds_u32 *)L.win;
     lds_u32 *const lut = (lds_u32 *)L.lut;
     for (int i = tid; i < AMP_NSYM * T_W; i += T_WAVES * 64) win[i] = 0;
-    if (tid == 0) L.dcount = 0;
+    if (tid == 0) { L.dcount = 0; L.dcount2 = 0; }
     if (tid < 16) { uint32_t c = col_of_code((uint32_t)tid); lut[tid] = c <= 4u ? c * (uint32_t)(T_W * 4) : 0u; }
     int32_t win_base = NO_WINDOW;
     lds_u32 *const st = (lds_u32 *)L.wv[wave].st;
@@ -722,12 +723,22 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             // A single hot counter in global memory would serialise the whole chip (one returning atomic
             // per tile); every block appends to its OWN segment of the list through an LDS counter.
-            const unsigned long long m = __ballot(has);
+            // Light entries (only deletions / insertion events left to do) fill the segment from the front,
+            // heavy ones (the whole read, or its exact status) from the back: two second-pass kernels.
+            const bool light = has && entry == ((uint32_t)i | DEFER_INDELS);
+            const unsigned long long m = __ballot(light), m2 = __ballot(has && !light);
             if (m) {
                 uint32_t dbase = 0;
                 if (lane == 0) dbase = __hip_atomic_fetch_add((lds_u32 *)&L.dcount, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 dbase = __shfl(dbase, 0);
-                if (has) dlist[(size_t)tile_begin * TILE + dbase + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+                if (light) dlist[(size_t)tile_begin * TILE + dbase + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+            }
+            if (m2) {
+                uint32_t dbase = 0;
+                if (lane == 0) dbase = __hip_atomic_fetch_add((lds_u32 *)&L.dcount2, (uint32_t)__popcll(m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                dbase = __shfl(dbase, 0);
+                if (has && !light)
+                    dlist[(size_t)(tile_begin + tiles_per_block) * TILE - 1 - (dbase + __popcll(m2 & ((1ull << lane) - 1ull)))] = entry;
             }
         }
         AMP_STAMP(4);
@@ -748,7 +759,10 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
-    if (tid == 0) { dcnt[blockIdx.x] = L.dcount; if (L.dcount) atomicAdd(&ctr[3], (unsigned long long)L.dcount); }
+    if (tid == 0) {
+        dcnt[blockIdx.x] = L.dcount; dcnt[5 * gridDim.x + 64 + blockIdx.x] = L.dcount2;
+        if (L.dcount + L.dcount2) atomicAdd(&ctr[3], (unsigned long long)(L.dcount + L.dcount2));
+    }
     if (stamps && lane == 0) {
         for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);
         atomicAdd(&ctr[6], t_loopend - t_kernel0);      // time a wave spends in its tile loop

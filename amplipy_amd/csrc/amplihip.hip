@@ -157,21 +157,100 @@ struct DevSink {
 };
 
 
+// Second-pass sink: the reads of one list segment come from one contiguous range of the sorted batch,
+// so their counts are privatised in a block-wide LDS window (device-scope atomics on distinct
+// addresses run at ~23 G/s chip-wide on MI355X: they, not the walk, bound a lane-per-read pass).
+// Positions outside the window go straight to the global table.
+constexpr uint32_t D_WIN = 512;
+constexpr uint32_t D_PLANES = AMP_NSYM + 1;   // six symbols + the insertion-event tally
+constexpr uint32_t D_EVCAP = 512;             // events staged per round (the rest go out one by one)
+struct WinSink {
+    lds_u32 *win;
+    int32_t base;
+    uint32_t *counts;
+    const EventBuf &eb;
+    uint32_t read;
+    lds_u32 *ev;      // [D_EVCAP][4] staged events
+    lds_u32 *nev;     // staging cursor (keeps counting past D_EVCAP)
+    __device__ void add(int32_t r, uint32_t col) {
+        const uint32_t d = (uint32_t)(r - base);
+        if (d < D_WIN) lds_add(win + col * D_WIN + d, 1u);
+        else atomicAdd(&counts[(size_t)r * AMP_NSYM + col], 1u);
+    }
+    // One returning atomic per event on the list cursor serialises in L2 (~0.2 events/ns chip-wide,
+    // measured): events are staged in LDS and the block reserves list space once per round.
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+        const uint32_t k = atomicAdd((uint32_t *)nev, 1u);
+        if (k < D_EVCAP) {
+            ev[k * 4] = (uint32_t)pos; ev[k * 4 + 1] = read; ev[k * 4 + 2] = (uint32_t)lo; ev[k * 4 + 3] = (uint32_t)hi;
+            const uint32_t d = (uint32_t)(pos - base);
+            if (d < D_WIN) lds_add(win + AMP_NSYM * D_WIN + d, 1u);
+            else atomicAdd(&eb.ins_at[pos], 1u);
+        } else {
+            eb.record(pos, read, lo, hi);
+        }
+    }
+};
+
+// Sink of the light second pass: a handful of '-' counts per read go straight to the table, events are staged.
+struct StageSink {
+    uint32_t *counts;
+    const EventBuf &eb;
+    uint32_t read;
+    lds_u32 *ev, *nev;
+    __device__ void add(int32_t r, uint32_t col) { atomicAdd(&counts[(size_t)r * AMP_NSYM + col], 1u); }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+        const uint32_t k = atomicAdd((uint32_t *)nev, 1u);
+        if (k < D_EVCAP) {
+            ev[k * 4] = (uint32_t)pos; ev[k * 4 + 1] = read; ev[k * 4 + 2] = (uint32_t)lo; ev[k * 4 + 3] = (uint32_t)hi;
+            atomicAdd(&eb.ins_at[pos], 1u);
+        } else {
+            eb.record(pos, read, lo, hi);
+        }
+    }
+};
+
+// Staged events -> the block's shard of the list, one reservation for all of them.  Block-wide.
+__device__ void flush_staged_events(const EventBuf &eb, const uint32_t *s_ev, uint32_t *s_nev, unsigned long long *s_evbase) {
+    __syncthreads();
+    const uint32_t nev = *s_nev < D_EVCAP ? *s_nev : D_EVCAP;
+    const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
+    if (threadIdx.x == 0 && nev) *s_evbase = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)nev);
+    __syncthreads();
+    if (nev) {
+        const unsigned long long eb0 = *s_evbase;
+        for (uint32_t k = threadIdx.x; k < nev; k += blockDim.x)
+            if ((long long)(eb0 + k) < eb.cap)
+                eb.ev[(size_t)shard * (size_t)eb.cap + eb0 + k] =
+                    amp_ins_event{(int32_t)s_ev[k * 4], s_ev[k * 4 + 1], (int32_t)s_ev[k * 4 + 2], (int32_t)s_ev[k * 4 + 3]};
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *s_nev = 0;
+    __syncthreads();
+}
+
 struct NullSink {   // dry run: only the status matters
     __device__ void add(int32_t, uint32_t) {}
     __device__ void event(int32_t, int32_t, int32_t) {}
 };
 
-// One read, start to finish, on one lane with the serial code of amp_read.hpp (CIGAR ping-pong
-// in global memory).  status_only: the tile kernel already counted this read and only needs
-// to know which error comes first in pair order.
-__device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
-                                    uint32_t *scratch, uint32_t *counts, const EventBuf &eb, bool status_only) {
-    const uint32_t c0 = rd.cig_off32[i];
-    const int n = (int)(rd.cig_off32[i + 1] - c0);
-    const size_t slot = (size_t)c0 + 3 * (size_t)i;
-    CigBuf<1> cur{out.new_cig + slot}, tmp{scratch + slot};
-    uint32_t *const home = cur.p;
+// one CIGAR column in LDS for the second pass (stride = block size)
+struct LdsCig256 {
+    lds_u32 *p;
+    __device__ __forceinline__ uint32_t get(int i) const { return p[i * 256]; }
+    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * 256] = v; }
+};
+
+__device__ __forceinline__ bool is_home(const CigBuf<1> &b, const uint32_t *home) { return b.p == home; }
+__device__ __forceinline__ bool is_home(const LdsCig256 &, const uint32_t *) { return false; }
+
+// One read, start to finish, on one lane with the serial code of amp_read.hpp.  cur / tmp are the
+// two CIGAR buffers the trims ping-pong between (global slots, or LDS columns when the read fits);
+// the final CIGAR always lands in the read's output slot.  status_only: the tile kernel already
+// counted this read and only needs to know which error comes first in pair order.
+template <class CB, class Sink>
+__device__ void process_read_body(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
+                                  const EventBuf &eb, bool status_only, CB cur, CB tmp, uint32_t *home, uint32_t c0, int n) {
     for (int k = 0; k < n; ++k) cur.set(k, rd.cig[c0 + k]);
     const int32_t lseq = (int32_t)rd.lseq[i];
     const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
@@ -179,18 +258,15 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
     const bool have_qual = lseq > 0 && qual[0] != 0xFF;
     TrimState st{rd.pos[i], n, 0u, 0};
     if (P.do_trim) trim_read_serial(P, st, rd.flag[i], rd.tlen[i], lseq, qual, have_qual, cur, tmp);
-    if (!st.err && cur.p != home) {
+    if (!st.err && !is_home(cur, home))
         for (int k = 0; k < st.n; ++k) home[k] = cur.get(k);
-        cur.p = home;
-    }
     int err = st.err;
     if (!err && P.do_count) {
         if (status_only) {
             NullSink ns;
-            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, ns);
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd.seq, boff, qual}, have_qual, ns);
         } else {
-            DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
-            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd.seq, boff, qual, have_qual, sink);
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd.seq, boff, qual}, have_qual, sink);
         }
     }
     if (out.new_pos) out.new_pos[i] = st.pos;
@@ -199,6 +275,109 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
     if (out.trim_flags) out.trim_flags[i] = st.err ? (uint8_t)0 : (uint8_t)st.flags;
     if (out.status) out.status[i] = (uint8_t)err;
     if (err) atomicAdd(&eb.ctr[2], 1ull);
+}
+
+// CIGAR ping-pong in global memory (any length)
+__device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
+                                    uint32_t *scratch, uint32_t *counts, const EventBuf &eb, bool status_only) {
+    const uint32_t c0 = rd.cig_off32[i];
+    const int n = (int)(rd.cig_off32[i + 1] - c0);
+    const size_t slot = (size_t)c0 + 3 * (size_t)i;
+    DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
+    process_read_body(P, rd, i, out, sink, eb, status_only, CigBuf<1>{out.new_cig + slot}, CigBuf<1>{scratch + slot},
+                      out.new_cig + slot, c0, n);
+}
+
+// Second-pass treatment of a read the tile kernel could not hold (more CIGAR ops than its LDS
+// column): serial trim with both CIGAR buffers in LDS columns, then
+//   * regular trimmed CIGAR (clips at the ends, body of M/=/X/I/D/N): deletions / insertion events by
+//     the skip-ahead walk on this lane; the match bases are left to the block's waves (count_match_coop)
+//     - returns true and leaves the final CIGAR in `cur`;
+//   * anything else: the exact serial walk.
+constexpr int D_MAXOPS = 20;
+struct QualAt { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } };
+
+template <class Sink>
+__device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
+                                      const EventBuf &eb, bool status_only, LdsCig256 &cur, LdsCig256 &tmp, uint32_t c0, int n,
+                                      int &n_final, int32_t &pos_final) {
+    uint32_t *const home = out.new_cig + (size_t)c0 + 3 * (size_t)i;
+    for (int k = 0; k < n; ++k) cur.set(k, rd.cig[c0 + k]);
+    const int32_t lseq = (int32_t)rd.lseq[i];
+    const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
+    const uint8_t *qual = rd.qual + boff;
+    const bool have_qual = lseq > 0 && qual[0] != 0xFF;
+    TrimState st{rd.pos[i], n, 0u, 0};
+    if (P.do_trim) trim_read_serial(P, st, rd.flag[i], rd.tlen[i], lseq, qual, have_qual, cur, tmp);
+    if (!st.err)
+        for (int k = 0; k < st.n; ++k) home[k] = cur.get(k);
+    int err = st.err;
+    bool coop = false;
+    if (!err && P.do_count) {
+        NullSink ns;
+        if (status_only) {
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd.seq, boff, qual}, have_qual, ns);
+        } else {
+            bool regular, plain;
+            int nseg, e1 = 0, e2 = 0;
+            int32_t qs = 0, qe = 0;
+            classify(cur, st.n, lseq, regular, plain, nseg);
+            if (!have_qual || lseq <= 0) regular = false;
+            if (regular) { qs = query_alignment_start(cur, st.n, lseq, e1); qe = query_alignment_end(cur, st.n, lseq, e2); }
+            if (regular && !e1 && !e2) {
+                if (!plain && count_regular_skip(P, cur, st.n, st.pos, lseq, qs, qe, QualAt{qual}, sink))
+                    err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd.seq, boff, qual}, have_qual, ns);
+                coop = err == 0;
+            } else {
+                err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd.seq, boff, qual}, have_qual, sink);
+            }
+        }
+    }
+    if (out.new_pos) out.new_pos[i] = st.pos;
+    if (out.new_ncig) out.new_ncig[i] = st.err ? 0u : (uint32_t)st.n;
+    if (out.ref_len) out.ref_len[i] = st.err ? 0 : reference_length(cur, st.n);
+    if (out.trim_flags) out.trim_flags[i] = st.err ? (uint8_t)0 : (uint8_t)st.flags;
+    if (out.status) out.status[i] = (uint8_t)err;
+    if (err) atomicAdd(&eb.ctr[2], 1ull);
+    n_final = st.n; pos_final = st.pos;
+    return coop;
+}
+
+// Match bases of one regular read by a group of D_GROUP lanes: lane = base of the current match op
+// (A:718, A:751-753); every op costs one memory round trip, so several reads per wave hide it.
+// A base that cannot be counted (code outside ACGTN, position past the table) makes the group's
+// first lane run the exact walk for the read's status, like the tile kernel's status-only deferral.
+constexpr int D_GROUP = 16;
+template <class Sink>
+__device__ void count_match_coop(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
+                                 const EventBuf &eb, const LdsCig256 &cig, int n, int32_t pos, int lane) {
+    const int32_t lseq = (int32_t)rd.lseq[i];
+    const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
+    const uint8_t *qual = rd.qual + boff;
+    const uint32_t G = (uint32_t)P.ref_len;
+    int32_t q = 0, r = pos;
+    bool bad = false;
+    for (int k = 0; k < n; ++k) {
+        const uint32_t v = cig.get(k), op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        if (is_match_op(op)) {
+            for (int32_t j = lane; j < len; j += D_GROUP) {
+                if ((int32_t)qual[q + j] < P.min_quality) continue;
+                const uint32_t col = code_to_col(base_code(rd.seq, boff, q + j));
+                if (col == 0xFFu || (uint32_t)(r + j) >= G) bad = true;
+                else sink.add(r + j, col);
+            }
+            q += len; r += len;
+        } else if (op == OP_I || op == OP_S) q += len;
+        else if (op == OP_D || op == OP_N) r += len;
+    }
+    const uint64_t gmask = ((1ull << D_GROUP) - 1ull) << ((threadIdx.x & 63u) & ~(uint32_t)(D_GROUP - 1));
+    if ((__ballot(bad) & gmask) && lane == 0) {
+        NullSink ns;
+        const int err = count_read_walk(P, cig, n, pos, lseq, ReadBytesCached{rd.seq, boff, qual}, true, ns);
+        if (out.status) out.status[i] = (uint8_t)err;
+        if (err) atomicAdd(&eb.ctr[2], 1ull);
+    }
 }
 
 // Variant 1: every read on its own lane.  Kept as the simple kernel the tile kernel is
@@ -210,24 +389,16 @@ k_reads_lane(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32
     process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, false);
 }
 
-// one CIGAR column in LDS for the second pass (stride = block size)
-struct LdsCig256 {
-    lds_u32 *p;
-    __device__ __forceinline__ uint32_t get(int i) const { return p[i * 256]; }
-    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * 256] = v; }
-};
-
 // Deletions / reference skips and insertion events of a read whose match bases the tile kernel
 // already counted: the skip-ahead walk over the FINAL CIGAR the tile kernel wrote out (staged in an
 // LDS column first: the walk re-reads ops many times).
-__device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, int64_t i, uint64_t read_base, const DevOut &out,
-                                   uint32_t *counts, const EventBuf &eb, lds_u32 *col) {
+template <class Sink>
+__device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink, lds_u32 *col) {
     const size_t slot = (size_t)rd.cig_off32[i] + 3 * (size_t)i;
     const int n = (int)out.new_ncig[i];
     const int32_t lseq = (int32_t)rd.lseq[i];
     const int32_t pos = out.new_pos[i];
     const uint8_t *qual = rd.qual + (int64_t)rd.seq_off8[i] * 8;
-    DevSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i)};
     struct Q { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } } qf{qual};
     int e1 = 0, e2 = 0;
     if (n <= T_MAXOPS) {
@@ -241,24 +412,101 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
     return count_regular_skip(P, cig, n, pos, lseq, qs, qe, qf, sink);
 }
 
-// Second pass of variant 2: the reads the tile kernel put on its deferred list, one per lane.
-// The list is dense, so the serial per-read code runs with every lane busy.
+// Second pass of variant 2, light half: reads whose match bases the tile kernel counted and that only
+// have deletions / insertion events left; one per lane off the front of the block's list segment.
 __global__ void __launch_bounds__(256)
-k_reads_deferred(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
+k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
                  EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
     __shared__ uint32_t s_cig[T_MAXOPS * 256];
-    // block b of this launch finishes the list segment written by block b of the tile kernel
+    __shared__ uint32_t s_ev[4 * D_EVCAP];
+    __shared__ uint32_t s_nev;
+    __shared__ unsigned long long s_evbase;
     const uint32_t cnt = dcnt[blockIdx.x];
+    if (cnt == 0) return;
     const uint32_t *seg = dlist + (size_t)blockIdx.x * (size_t)tiles_per_block * TILE;
-    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
-        const uint32_t e = seg[k];
-        const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
-        bool status_only = (e & DEFER_STATUS_ONLY) != 0;
-        if (e & DEFER_INDELS) {
-            if (process_read_indels(P, rd, i, read_base, out, counts, eb, (lds_u32 *)s_cig + threadIdx.x)) status_only = true;   // exact status below
-            else if (!status_only) continue;
+    if (threadIdx.x == 0) s_nev = 0;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < cnt; k0 += blockDim.x) {
+        const uint32_t k = k0 + threadIdx.x;
+        if (k < cnt) {
+            const int64_t i = (int64_t)(seg[k] & DEFER_INDEX_MASK);
+            StageSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
+            if (process_read_indels(P, rd, i, out, sink, (lds_u32 *)s_cig + threadIdx.x))
+                process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, true);   // exact status
         }
-        process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, status_only);
+        flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
+    }
+}
+
+// Heavy half, off the back of the segment: reads the tile kernel could not take at all (more CIGAR ops
+// than its LDS column, unusual CIGAR, no room in the tile's segment table) and reads that need
+// their exact status.  Lane = read for trimming and indels, lane groups for match bases.
+__global__ void __launch_bounds__(256)
+k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
+    __shared__ uint32_t s_cig[2 * D_MAXOPS * 256];
+    __shared__ uint32_t s_win[D_PLANES * D_WIN];
+    __shared__ uint32_t s_coop[3 * 256];
+    __shared__ uint32_t s_ev[4 * D_EVCAP];
+    __shared__ uint32_t s_ncoop, s_nev;
+    __shared__ unsigned long long s_evbase;
+    const uint32_t cnt = dcnt[5 * gridDim.x + 64 + blockIdx.x];
+    if (cnt == 0) return;
+    const uint32_t *seg_end = dlist + ((size_t)blockIdx.x + 1) * (size_t)tiles_per_block * TILE;
+    for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
+    if (threadIdx.x == 0) { s_ncoop = 0; s_nev = 0; }
+    // sorted input: no read of this block starts left of the first read of its tile range
+    int32_t base = rd.pos[(int64_t)blockIdx.x * tiles_per_block * TILE];
+    if (base < 0) base = 0;
+    __syncthreads();
+    uint32_t done = 0;   // cooperative entries of earlier rounds (the LDS cursor keeps counting)
+    for (uint32_t k0 = 0; k0 < cnt; k0 += blockDim.x) {
+        const uint32_t k = k0 + threadIdx.x;
+        if (k < cnt) {
+            const uint32_t e = seg_end[-1 - (int64_t)k];
+            const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
+            bool status_only = (e & DEFER_STATUS_ONLY) != 0, more = true;
+            WinSink sink{(lds_u32 *)s_win, base, counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
+            if (e & DEFER_INDELS) {
+                if (process_read_indels(P, rd, i, out, sink, (lds_u32 *)s_cig + threadIdx.x)) status_only = true;   // exact status below
+                else if (!status_only) more = false;
+            }
+            if (more) {
+                const uint32_t c0 = rd.cig_off32[i];
+                const int n = (int)(rd.cig_off32[i + 1] - c0);
+                if (n + 3 <= D_MAXOPS) {
+                    LdsCig256 cur{(lds_u32 *)s_cig + threadIdx.x}, tmp{(lds_u32 *)s_cig + D_MAXOPS * 256 + threadIdx.x};
+                    int nf; int32_t pf;
+                    if (process_read_full_lds(P, rd, i, out, sink, eb, status_only, cur, tmp, c0, n, nf, pf)) {
+                        const uint32_t slot = atomicAdd(&s_ncoop, 1u) - done;
+                        const uint32_t in_b = cur.p != (lds_u32 *)s_cig + threadIdx.x;
+                        s_coop[slot * 3] = (uint32_t)i;
+                        s_coop[slot * 3 + 1] = (uint32_t)nf | (in_b << 8) | (threadIdx.x << 16);
+                        s_coop[slot * 3 + 2] = (uint32_t)pf;
+                    }
+                } else {
+                    process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, status_only);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t ncoop = s_ncoop - done;
+        for (uint32_t c = threadIdx.x / D_GROUP; c < ncoop; c += blockDim.x / D_GROUP) {
+            const int64_t i = (int64_t)s_coop[c * 3];
+            const uint32_t w = s_coop[c * 3 + 1];
+            WinSink sink{(lds_u32 *)s_win, base, counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
+            const LdsCig256 cig{(lds_u32 *)s_cig + ((w >> 8) & 1u) * (D_MAXOPS * 256) + (w >> 16)};
+            count_match_coop(P, rd, i, out, sink, eb, cig, (int)(w & 0xFFu), (int32_t)s_coop[c * 3 + 2], (int)(threadIdx.x % D_GROUP));
+        }
+        done += ncoop;
+        flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
+    }
+    for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) {
+        const uint32_t v = s_win[k];
+        if (!v) continue;
+        const uint32_t plane = k / D_WIN, p = (uint32_t)base + k % D_WIN;
+        if (plane < AMP_NSYM) atomicAdd(&counts[(size_t)p * AMP_NSYM + plane], v);
+        else atomicAdd(&eb.ins_at[p], v);
     }
 }
 
@@ -609,11 +857,11 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
     const TileGrid tg = tile_grid(n, c->n_cu);
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid * 5 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid * 6 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
     uint32_t *dcnt = dlist + (size_t)tg.grid * (size_t)tg.tpb * TILE;  // entries used in each segment
-    uint32_t *extra = dcnt + tg.grid * 5 + 64;
+    uint32_t *extra = dcnt + tg.grid * 6 + 64;           // [grid] light counts | 64 | [4*grid] debug | [grid] heavy counts
     c->dbg_dcnt = dcnt; c->dbg_grid = (int)tg.grid;
     if (c->phases & 0x100u) HIPCHK(c, hipMemsetAsync(dcnt, 0, ((size_t)tg.grid * 5 + 64) * 4, c->stream));
     if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
@@ -634,7 +882,10 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_reads_deferred<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
+        k_deferred_light<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
+                                                                   (long long)tg.tpb);
+        HIPCHK(c, hipGetLastError());
+        k_deferred_heavy<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
                                                                    (long long)tg.tpb);
         HIPCHK(c, hipGetLastError());
     }

@@ -48,7 +48,7 @@ extern "C" int sim_process_range(int32_t min_quality, int32_t window, int32_t do
         int err = st.err;
         if (!err && do_count) {
             HostSink sink{counts, &ev, (uint32_t)(read_base + (uint64_t)i)};
-            err = count_read_walk(P, cur, st.n, st.pos, lseq, rd->seq, boff, qual, have_qual, sink);
+            err = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytesCached{rd->seq, boff, qual}, have_qual, sink);
         }
         if (out && out->status) out->status[i] = (uint8_t)err;
     }
