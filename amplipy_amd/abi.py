@@ -53,6 +53,11 @@ class AmpCallParams(C.Structure):
                 ("full_ranking", C.c_int32), ("reserved", C.c_int32)]
 
 
+class AmpCallView(C.Structure):
+    _fields_ = [("consensus", C.c_void_p), ("vars", C.c_void_p), ("relevant", C.c_void_p),
+                ("n_vars", C.c_int64), ("n_relevant", C.c_int64)]
+
+
 POS_CALL_DTYPE = np.dtype([("total_depth", "<u4"), ("ref_count", "<u4"), ("order", "<u4"), ("consensus_sym", "i1"),
                            ("flags", "u1"), ("alt_mask", "u1"), ("pad", "u1")])
 CALL_VARIANT, CALL_GT_HAS_REF, CALL_INS_RELEVANT = 1, 2, 4

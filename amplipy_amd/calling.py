@@ -37,6 +37,9 @@ class VariantRecord:
                 "REF_FREQ": float(self.REF_FREQ).hex(), "ALT_FREQ": self.ALT_FREQ, "GT": list(self.GT)}
 
 
+_CONS_LUT = {}
+
+
 class CallResult:
     """Columnar outcome of calling.
 
@@ -76,11 +79,17 @@ class CallResult:
 
     def consensus_string(self, unknown_symbol="N"):
         """''.join(consensus_symbols) of AmpliPy.py:960."""
-        lut = np.frombuffer((SYMS + unknown_symbol).encode("ascii"), np.uint8)
-        idx = np.where(self.consensus_sym >= 0, self.consensus_sym, 6).astype(np.int64)
+        lut = _CONS_LUT.get(unknown_symbol) if len(unknown_symbol) == 1 else None
+        if lut is None:
+            if len(unknown_symbol) != 1:
+                return "".join(unknown_symbol if c is None else c for c in self.consensus)
+            lut = np.full(256, ord(unknown_symbol), np.uint8)       # negative codes (as uint8) -> unknown
+            lut[:6] = np.frombuffer(SYMS.encode("ascii"), np.uint8)
+            _CONS_LUT[unknown_symbol] = lut
+        text = lut[self.consensus_sym.view(np.uint8)]
         if not self.consensus_ins:
-            return lut[idx].tobytes().decode("ascii")
-        parts = [chr(c) for c in lut[idx]]
+            return text.tobytes().decode("ascii")
+        parts = [chr(c) for c in text]
         for p, s in self.consensus_ins.items():
             parts[p] = s
         return "".join(parts)
@@ -143,8 +152,8 @@ def result_from_compact(ref_seq, cp, cons, vr):
     """CallResult from the arrays of Engine.call_compact when no position needs insertion alleles."""
     if not cp.run_consensus:
         cons = np.full(cons.size, -1, np.int8)
-    return CallResult(ref_seq, cons, {}, vr["pos"], vr["total_depth"], vr["ref_count"], vr["gt_has_ref"] != 0,
-                      vr["n_alt"].astype(np.int8), vr["alt_col"].view(np.int8), vr["alt_count"], {}, None, 0)
+    return CallResult(ref_seq, cons, {}, vr["pos"], vr["total_depth"], vr["ref_count"], vr["gt_has_ref"].view(np.bool_),
+                      vr["n_alt"].view(np.int8), vr["alt_col"].view(np.int8), vr["alt_count"], {}, None, 0)
 
 
 def call(engine, ref_seq, cp, ins_strings_at=None, want_alleles=False, positions=None):

@@ -295,7 +295,21 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
 constexpr int D_MAXOPS = 20;
-struct QualAt { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } };
+// qualities through an 8-byte register cache (reads start on 8-byte boundaries): the bases of an
+// insertion cost one or two memory round trips instead of one each
+struct QualAt {
+    const uint8_t *q;
+    mutable int32_t blk = -1;
+    mutable uint32_t lo = 0, hi = 0;
+    __device__ uint32_t operator()(int32_t k) const {
+        if ((k >> 3) != blk) {
+            blk = k >> 3;
+            const uint2 v = *(const uint2 *)(q + (int64_t)blk * 8);
+            lo = v.x; hi = v.y;
+        }
+        return (((k & 4) ? hi : lo) >> ((k & 3) * 8)) & 0xFFu;
+    }
+};
 
 template <class Sink>
 __device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
@@ -399,7 +413,7 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
     const int32_t lseq = (int32_t)rd.lseq[i];
     const int32_t pos = out.new_pos[i];
     const uint8_t *qual = rd.qual + (int64_t)rd.seq_off8[i] * 8;
-    struct Q { const uint8_t *q; __device__ uint32_t operator()(int32_t k) const { return q[k]; } } qf{qual};
+    const QualAt qf{qual};
     int e1 = 0, e2 = 0;
     if (n <= T_MAXOPS) {
         const LdsCig256 cig{col};
@@ -416,18 +430,27 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
 // have deletions / insertion events left; one per lane off the front of the block's list segment.
 __global__ void __launch_bounds__(256)
 k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
     __shared__ uint32_t s_cig[T_MAXOPS * 256];
     __shared__ uint32_t s_ev[4 * D_EVCAP];
     __shared__ uint32_t s_nev;
     __shared__ unsigned long long s_evbase;
-    const uint32_t cnt = dcnt[blockIdx.x];
-    if (cnt == 0) return;
-    const uint32_t *seg = dlist + (size_t)blockIdx.x * (size_t)tiles_per_block * TILE;
+    // one wave per list segment, four segments per block (a segment rarely fills a whole block)
+    const int64_t sb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = sb < n_seg ? dcnt[sb] : 0u;
+    uint32_t cmax = 0;
+    for (int w = 0; w < 4; ++w) {
+        const int64_t s2 = (int64_t)blockIdx.x * 4 + w;
+        const uint32_t c2 = s2 < n_seg ? dcnt[s2] : 0u;
+        cmax = c2 > cmax ? c2 : cmax;
+    }
+    if (cmax == 0) return;
+    const uint32_t *seg = dlist + (size_t)sb * (size_t)tiles_per_block * TILE;
     if (threadIdx.x == 0) s_nev = 0;
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < cnt; k0 += blockDim.x) {
-        const uint32_t k = k0 + threadIdx.x;
+    for (uint32_t k0 = 0; k0 < cmax; k0 += 64) {
+        const uint32_t k = k0 + lane;
         if (k < cnt) {
             const int64_t i = (int64_t)(seg[k] & DEFER_INDEX_MASK);
             StageSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
@@ -443,20 +466,34 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
 // their exact status.  Lane = read for trimming and indels, lane groups for match bases.
 __global__ void __launch_bounds__(256)
 k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block) {
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
     __shared__ uint32_t s_cig[2 * D_MAXOPS * 256];
     __shared__ uint32_t s_win[D_PLANES * D_WIN];
     __shared__ uint32_t s_coop[3 * 256];
     __shared__ uint32_t s_ev[4 * D_EVCAP];
     __shared__ uint32_t s_ncoop, s_nev;
     __shared__ unsigned long long s_evbase;
-    const uint32_t cnt = dcnt[5 * gridDim.x + 64 + blockIdx.x];
-    if (cnt == 0) return;
-    const uint32_t *seg_end = dlist + ((size_t)blockIdx.x + 1) * (size_t)tiles_per_block * TILE;
+    // Few reads are heavy: a small persistent grid looks at 64 segment counts per wave-load and only
+    // enters segments that have entries (a block per segment would cost more in empty launches).
+    __shared__ unsigned long long s_mask;
+    for (int64_t sb0 = blockIdx.x; sb0 < n_seg; sb0 += (int64_t)gridDim.x * 64) {
+    if (threadIdx.x < 64) {
+        const int64_t sbl = sb0 + (int64_t)threadIdx.x * gridDim.x;
+        const unsigned long long mk = __ballot(sbl < n_seg && dcnt[5 * n_seg + 64 + sbl] != 0);
+        if (threadIdx.x == 0) s_mask = mk;
+    }
+    __syncthreads();
+    unsigned long long todo = s_mask;
+    __syncthreads();
+    while (todo) {
+    const int64_t sb = sb0 + (int64_t)(__ffsll((long long)todo) - 1) * gridDim.x;
+    todo &= todo - 1;
+    const uint32_t cnt = dcnt[5 * n_seg + 64 + sb];
+    const uint32_t *seg_end = dlist + ((size_t)sb + 1) * (size_t)tiles_per_block * TILE;
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
     if (threadIdx.x == 0) { s_ncoop = 0; s_nev = 0; }
-    // sorted input: no read of this block starts left of the first read of its tile range
-    int32_t base = rd.pos[(int64_t)blockIdx.x * tiles_per_block * TILE];
+    // sorted input: no read of this segment starts left of the first read of its tile range
+    int32_t base = rd.pos[sb * tiles_per_block * TILE];
     if (base < 0) base = 0;
     __syncthreads();
     uint32_t done = 0;   // cooperative entries of earlier rounds (the LDS cursor keeps counting)
@@ -508,6 +545,9 @@ k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
         if (plane < AMP_NSYM) atomicAdd(&counts[(size_t)p * AMP_NSYM + plane], v);
         else atomicAdd(&eb.ins_at[p], v);
     }
+    __syncthreads();
+    }   // segments of this round
+    }   // rounds
 }
 
 __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
@@ -877,16 +917,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
     } else {
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr[3], 0, sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_deferred_light<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
-                                                                   (long long)tg.tpb);
+        k_deferred_light<<<(unsigned)((tg.grid + 3) / 4), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
+                                                                               (long long)tg.tpb, (long long)tg.grid);
         HIPCHK(c, hipGetLastError());
-        k_deferred_heavy<<<(unsigned)tg.grid, 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
-                                                                   (long long)tg.tpb);
+        k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
+            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, (long long)tg.tpb, (long long)tg.grid);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
@@ -1101,60 +1140,67 @@ int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out,
     return AMP_OK;
 }
 
-int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, amp_var_rec *vars, int64_t vars_cap,
-                     int64_t *n_vars, int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant) {
-    if (!c || !pr || !consensus || !n_vars || !n_relevant || vars_cap < 0 || relevant_cap < 0) return AMP_EINVAL;
+int amp_call_compact_view(amp_ctx *c, const amp_call_params *pr, amp_call_view *view) {
+    if (!c || !pr || !view) return AMP_EINVAL;
     if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
     Guard g(c);
     const int32_t G = c->ref_len;
-    const size_t off_cons = (size_t)G * sizeof(amp_pos_call);
-    const size_t off_vars = (off_cons + (size_t)G + 63) & ~(size_t)63;
-    const size_t off_rel = off_vars + (size_t)G * sizeof(amp_var_rec);
-    const size_t off_blk = off_rel + (size_t)G * 4;
+    // device buffer: [per-position calls][block counts] | output image [totals 64 B][consensus][records][relevant positions]
+    // The output image has the same layout in the pinned host buffer, so its used prefix travels in ONE copy.
     const unsigned nblk = (unsigned)((G + 255) / 256);
-    HIPCHK(c, c->call_buf.ensure(off_blk + (size_t)nblk * sizeof(uint2) + 64));
-    uint8_t *base = c->call_buf.as<uint8_t>();
+    const size_t off_blk = (size_t)G * sizeof(amp_pos_call);
+    const size_t off_img = (off_blk + (size_t)nblk * sizeof(uint2) + 63) & ~(size_t)63;
+    const size_t img_cons = 64, img_vars = img_cons + (((size_t)G + 63) & ~(size_t)63);
+    const size_t img_rel = img_vars + (size_t)G * sizeof(amp_var_rec), img_size = img_rel + (size_t)G * 4;
+    HIPCHK(c, c->call_buf.ensure(off_img + img_size + 64));
+    uint8_t *base = c->call_buf.as<uint8_t>(), *img = base + off_img;
     amp_pos_call *d_pc = (amp_pos_call *)base;
     k_call<<<nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + off_blk));
     HIPCHK(c, hipGetLastError());
-    k_call_compact<<<nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + off_blk), (int8_t *)(base + off_cons),
-                                                (amp_var_rec *)(base + off_vars), (int32_t *)(base + off_rel), &c->d_ctr[5]);
+    k_call_compact<<<nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + off_blk), (int8_t *)(img + img_cons),
+                                                (amp_var_rec *)(img + img_vars), (int32_t *)(img + img_rel), (unsigned long long *)img);
     HIPCHK(c, hipGetLastError());
-    // one pinned round trip: totals + consensus + as many records as the previous call produced
-    // (plus a margin); a second copy only when this call produced more
-    const size_t pin_need = 64 + (size_t)G + (size_t)G * sizeof(amp_var_rec) + (size_t)G * 4;
-    if (c->h_pin_cap < pin_need) {
+    if (c->h_pin_cap < img_size) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         c->h_pin = nullptr; c->h_pin_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_pin, pin_need, hipHostMallocDefault));
-        c->h_pin_cap = pin_need;
+        HIPCHK(c, hipHostMalloc(&c->h_pin, img_size, hipHostMallocDefault));
+        c->h_pin_cap = img_size;
     }
     uint8_t *hp = (uint8_t *)c->h_pin;
-    unsigned long long *h_nn = (unsigned long long *)hp;
-    int8_t *h_cons = (int8_t *)(hp + 64);
-    amp_var_rec *h_vars = (amp_var_rec *)(hp + 64 + (((size_t)G + 63) & ~(size_t)63));
-    int32_t *h_rel = (int32_t *)((uint8_t *)h_vars + (size_t)G * sizeof(amp_var_rec));
+    const unsigned long long *h_nn = (const unsigned long long *)hp;
+    const int8_t *h_cons = (const int8_t *)(hp + img_cons);
+    amp_var_rec *h_vars = (amp_var_rec *)(hp + img_vars);
+    int32_t *h_rel = (int32_t *)(hp + img_rel);
+    // as many records as the previous call produced (plus a margin); more copies only when this call produced more
     const int64_t guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
-    const int64_t guess_r = std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64);
-    HIPCHK(c, hipMemcpyAsync(h_nn, &c->d_ctr[5], 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_cons, base + off_cons, (size_t)G, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_vars, base + off_vars, (size_t)guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_rel, base + off_rel, (size_t)guess_r * 4, hipMemcpyDeviceToHost, c->stream));
+    const int64_t guess_r = c->last_nr ? std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64) : 0;
+    HIPCHK(c, hipMemcpyAsync(hp, img, img_vars + (size_t)guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+    if (guess_r) HIPCHK(c, hipMemcpyAsync(h_rel, img + img_rel, (size_t)guess_r * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int64_t nv = (int64_t)h_nn[0], nr = (int64_t)h_nn[1];
-    *n_vars = nv; *n_relevant = nr;
     c->last_nv = nv; c->last_nr = nr;
-    if (nv > vars_cap || nr > relevant_cap) return AMP_EOVERFLOW;
     if (nv > guess_v || nr > guess_r) {
-        if (nv > guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + guess_v, base + off_vars + (size_t)guess_v * sizeof(amp_var_rec),
+        if (nv > guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + guess_v, img + img_vars + (size_t)guess_v * sizeof(amp_var_rec),
                                                    (size_t)(nv - guess_v) * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-        if (nr > guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + guess_r, base + off_rel + (size_t)guess_r * 4, (size_t)(nr - guess_r) * 4,
+        if (nr > guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + guess_r, img + img_rel + (size_t)guess_r * 4, (size_t)(nr - guess_r) * 4,
                                                    hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    memcpy(consensus, h_cons, (size_t)G);
-    if (nv && vars) memcpy(vars, h_vars, (size_t)nv * sizeof(amp_var_rec));
-    if (nr && relevant) memcpy(relevant, h_rel, (size_t)nr * 4);
+    *view = amp_call_view{h_cons, h_vars, h_rel, nv, nr};
+    return AMP_OK;
+}
+
+int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, amp_var_rec *vars, int64_t vars_cap,
+                     int64_t *n_vars, int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant) {
+    if (!c || !pr || !consensus || !n_vars || !n_relevant || vars_cap < 0 || relevant_cap < 0) return AMP_EINVAL;
+    amp_call_view v;
+    const int rc = amp_call_compact_view(c, pr, &v);
+    if (rc != AMP_OK) return rc;
+    *n_vars = v.n_vars; *n_relevant = v.n_relevant;
+    if (v.n_vars > vars_cap || v.n_relevant > relevant_cap) return AMP_EOVERFLOW;
+    memcpy(consensus, v.consensus, (size_t)c->ref_len);
+    if (v.n_vars && vars) memcpy(vars, v.vars, (size_t)v.n_vars * sizeof(amp_var_rec));
+    if (v.n_relevant && relevant) memcpy(relevant, v.relevant, (size_t)v.n_relevant * 4);
     return AMP_OK;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view",
 ]
 
 
@@ -207,20 +207,24 @@ class Engine:
         return out, int(nr.value)
 
     def call_compact(self, params):
-        """amp_call_compact -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R]).  The arrays
-        are views of buffers owned by the engine, valid until the next call."""
+        """amp_call_compact_view -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R]).  The arrays
+        are views of page-locked memory owned by the engine, valid until the next call_* on it."""
         G = self.ref_len
-        if not hasattr(self, "_cc"):
-            bufs = (np.zeros(G, np.int8), np.zeros(G, abi.VAR_REC_DTYPE), np.zeros(G, np.int32))
-            nv = C.c_int64(0); nr = C.c_int64(0)
-            args = (C.c_void_p(abi.ptr(bufs[0])), C.c_void_p(abi.ptr(bufs[1])), C.c_int64(G), C.byref(nv),
-                    C.c_void_p(abi.ptr(bufs[2])), C.c_int64(G), C.byref(nr))
-            self._cc = (bufs, nv, nr, args)
-        bufs, nv, nr, args = self._cc
-        rc = self.L.amp_call_compact(self.h, C.byref(params), *args)
+        if not hasattr(self, "_cv"):
+            self._cv = [abi.AmpCallView(), None, None]
+        st = self._cv
+        v = st[0]
+        rc = self.L.amp_call_compact_view(self.h, C.byref(params), C.byref(v))
         if rc:
-            self._chk(rc, "amp_call_compact")
-        return bufs[0], bufs[1][:nv.value], bufs[2][:nr.value]
+            self._chk(rc, "amp_call_compact_view")
+        key = (v.consensus, v.vars, v.relevant)
+        if st[1] != key:   # (re)wrap the library's image once per allocation
+            cons = np.frombuffer((C.c_int8 * G).from_address(v.consensus), np.int8)
+            vars_ = np.frombuffer((C.c_uint8 * (G * abi.VAR_REC_DTYPE.itemsize)).from_address(v.vars), abi.VAR_REC_DTYPE)
+            rel = np.frombuffer((C.c_int32 * G).from_address(v.relevant), np.int32)
+            st[1] = key; st[2] = (cons, vars_, rel)
+        cons, vars_, rel = st[2]
+        return cons, vars_[:v.n_vars], rel[:v.n_relevant]
 
     def event_strings_device(self, dev_reads, events, read_base=0):
         """Strings of ``events`` (INS_EVENT_DTYPE) taken from a device-resident batch."""

@@ -270,6 +270,15 @@ int amp_call_positions(amp_ctx *ctx, const amp_call_params *params, amp_pos_call
 int amp_call_compact(amp_ctx *ctx, const amp_call_params *params, int8_t *consensus /* [ref_len] */,
                      amp_var_rec *vars, int64_t vars_cap, int64_t *n_vars,
                      int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant);
+/* amp_call_compact without the last copy: the arrays stay in page-locked memory owned by ctx and
+ * are valid until the next amp_call_* on the same ctx (or amp_ctx_destroy). */
+typedef struct amp_call_view {
+    const int8_t *consensus;       /* [ref_len] */
+    const amp_var_rec *vars;       /* [n_vars] */
+    const int32_t *relevant;       /* [n_relevant] */
+    int64_t n_vars, n_relevant;
+} amp_call_view;
+int amp_call_compact_view(amp_ctx *ctx, const amp_call_params *params, amp_call_view *out);
 /* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
  * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host. */
 int amp_event_strings(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int64_t n_events,
