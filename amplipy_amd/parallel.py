@@ -33,6 +33,18 @@ def reduce_table(dist, table, dst=0):
     dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)
 
 
+def allreduce_table(dist, table):
+    """Sum the device table on every rank (each can then make the calls itself: no second collective)."""
+    dist.all_reduce(table, op=dist.ReduceOp.SUM)
+
+
+def allgather_relevant_events(dist, world, pairs):
+    """Union of [(ref_pos, string)] lists on every rank."""
+    gathered = [None] * world
+    dist.all_gather_object(gathered, pairs)
+    return [p for part in gathered for p in part]
+
+
 def gather_relevant_events(dist, rank, world, pairs, dst=0):
     """Union of [(ref_pos, string)] lists on ``dst`` (other ranks get [])."""
     gathered = [None] * world if rank == dst else None

@@ -54,6 +54,55 @@ def _worker(rank, world, port, n_reads, out_path):
         dist.destroy_process_group()
 
 
+def _worker_allreduce(rank, world, port, n_reads, out_dir):
+    """The bench's protocol: ONE all-reduce, then every rank decides the relevant positions from the
+    same table and the insertion strings are exchanged symmetrically."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+        pr = [(s, e) for s, e, _ in primers]
+        mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, 0)
+        batch = synth.make_amplicon_batch(g, amps, n_reads, seed=78)
+        cuts = parallel.shard_bounds(batch, world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        mine = batch.slice(lo, hi)
+        r = oracle.process(mine, g.size, mn, mx, mpl, 20, 4, read_base=lo)
+        table = np.zeros(g.size * 7, np.int64)
+        table[:g.size * 6] = r.counts.reshape(-1)
+        np.add.at(table[g.size * 6:], r.events["ref_pos"], 1)
+        t = torch.from_numpy(table.astype(np.int32))
+        parallel.allreduce_table(dist, t)
+        rel = [int(p) for p in np.nonzero(t.numpy()[g.size * 6:])[0][::89]]     # same on every rank by construction
+        ev = r.events[np.isin(r.events["ref_pos"], rel)]
+        ev_local = ev.copy(); ev_local["read"] -= lo
+        allpairs = parallel.allgather_relevant_events(dist, world, event_strings(mine, ev_local))
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), table=t.numpy(), rel=np.array(rel),
+                 pairs=np.array(sorted(allpairs), dtype=object))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_protocol_gives_every_rank_the_whole_result(tmp_path):
+    world, n_reads = 2, 5000
+    mp.spawn(_worker_allreduce, args=(world, _free_port(), n_reads, str(tmp_path)), nprocs=world, join=True)
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    pr = [(s, e) for s, e, _ in primers]
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, 0)
+    batch = synth.make_amplicon_batch(g, amps, n_reads, seed=78)
+    ref = oracle.process(batch, g.size, mn, mx, mpl, 20, 4)
+    tally = np.zeros(g.size, np.int64); np.add.at(tally, ref.events["ref_pos"], 1)
+    for rank in range(world):
+        got = np.load(str(tmp_path / ("r%d.npz" % rank)), allow_pickle=True)
+        table = got["table"].view(np.uint32)
+        assert np.array_equal(table[:g.size * 6].reshape(g.size, 6), ref.counts)
+        assert np.array_equal(table[g.size * 6:], tally.astype(np.uint32))
+        rel = set(int(p) for p in got["rel"])
+        assert rel, "the sample should have insertion events"
+        want = sorted(p for p in event_strings(batch, ref.events) if p[0] in rel)
+        assert [tuple(x) for x in got["pairs"]] == want
+
+
 @pytest.mark.parametrize("world", [2])
 def test_sharded_reduce_matches_single_process(tmp_path, world):
     n_reads = 6000
