@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import argparse
 import gzip
+import os
 import sys
 from datetime import datetime
 from os.path import isfile
@@ -104,6 +105,25 @@ def open_alignment_files(input_fn, output_fn):
     return reader, writer
 
 
+def open_native_bam(input_fn, output_fn):
+    """(BamFile, BamWriter or None) when the native codec can serve this run: BAM file in, and BAM file
+    (or nothing) out.  None otherwise (SAM text, stdin / stdout): the Python codec handles those.
+    Same checks and messages as open_alignment_files."""
+    if input_fn is None or input_fn.lower() == "stdin" or not isfile(input_fn) or _reads_mode(input_fn, False) != "rb":
+        return None
+    if output_fn is not None and (output_fn.lower() == "stdout" or isfile(output_fn) or _reads_mode(output_fn, True) != "wb"):
+        return None
+    if os.environ.get("AMPLIPY_PYTHON_BAM"):
+        return None
+    from . import bam_native
+    src = bam_native.BamFile(input_fn)
+    writer = None
+    if output_fn is not None:
+        hdr = bamio.Header(src.header_text, src.references).with_amplipy_pg(VERSION, " ".join(sys.argv))
+        writer = bam_native.BamWriter(output_fn, hdr.text, src)
+    return src, writer
+
+
 class VcfWriter:
     """Text VCF with the header AmpliPy builds through pysam (AmpliPy.py:271-281)."""
 
@@ -188,13 +208,18 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         print_log("Precalculating overlapping primers...")
         mn, mx, mpl = lib.find_overlapping_primers(G, primers, primer_pos_offset)
         eng.set_primers(mn, mx, mpl)
+    native = None
     if run_trim:
         print_log("Input untrimmed SAM/BAM: %s" % untrimmed_reads_fn)
         print_log("Output trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
+        native = open_native_bam(untrimmed_reads_fn, trimmed_reads_fn)
+        if native is None:
+            reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
     else:
         print_log("Input trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        reader, writer = open_alignment_files(trimmed_reads_fn, None)
+        native = open_native_bam(trimmed_reads_fn, None)
+        if native is None:
+            reader, writer = open_alignment_files(trimmed_reads_fn, None)
     vcf = None
     if variants_fn is not None:
         print_log("Output variants VCF: %s" % variants_fn)
@@ -230,18 +255,48 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         read_base += batch.n
         del pending[:]
 
-    for s_i, rec in enumerate(reader):
-        if s_i % PROGRESS_NUM_READS == 0 and s_i != 0:
-            print_log("Processed %d reads..." % s_i)
-        if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
-            continue
-        pending.append(rec)
-        if len(pending) >= BATCH_READS:
-            flush()
-    flush()
-    if writer is not None:
-        writer.close()
-    reader.close()
+    if native is not None:
+        # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
+        # re-encodes the kept ones; no per-read Python object exists on this path
+        src, nwriter = native
+        for first in range(0, src.n_records, BATCH_READS):
+            count = min(BATCH_READS, src.n_records - first)
+            batch, _ = src.decode(first, count)
+            for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
+                if s_i:
+                    print_log("Processed %d reads..." % s_i)
+            s_i = first + count - 1
+            if batch.n == 0:
+                continue
+            res = eng.process(batch, read_base=read_base)
+            bad = np.nonzero(res.status)[0]
+            if len(bad):
+                _raise_for_status(res.status[bad[0]])
+            if run_trim and nwriter is not None:
+                keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
+                slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
+                nwriter.write_rows(batch.src_index, keep, res.new_pos, res.new_ncig, slot_off, res.new_cig)
+            if do_count:
+                ev = eng.events()
+                new = ev[ev["read"] >= read_base] if read_base else ev
+                ins_pairs.extend(event_strings(batch, new, read_base))
+            read_base += batch.n
+        if nwriter is not None:
+            nwriter.close()
+        src.close()
+    else:
+        for s_i, rec in enumerate(reader):
+            if s_i % PROGRESS_NUM_READS == 0 and s_i != 0:
+                print_log("Processed %d reads..." % s_i)
+            if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
+                continue
+            pending.append(rec)
+            if len(pending) >= BATCH_READS:
+                flush()
+        flush()
+        if writer is not None:
+            writer.close()
+        reader.close()
 
     if do_count:
         cp = calling.call_params(min_depth_consensus if min_depth_consensus is not None else 0,

@@ -1,4 +1,5 @@
-"""In-tree build of libamplihip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""In-tree build of libamplihip.so with hipcc for gfx950 (cross-compiles without a GPU) and of the
+host-side BAM codec libampbam.so (g++, zlib)."""
 from __future__ import annotations
 
 import os
@@ -31,5 +32,21 @@ def build(force=False, verbose=False, extra_flags=()):
     return OUT
 
 
+BAM_SRC = os.path.join(_HERE, "csrc", "ampbam.cpp")
+BAM_DEPS = [BAM_SRC, os.path.join(_HERE, "..", "include", "ampbam.h")]
+BAM_OUT = os.path.join(_HERE, "libampbam.so")
+
+
+def build_bam(force=False, verbose=False):
+    if not force and os.path.isfile(BAM_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(BAM_OUT) for d in BAM_DEPS):
+        return BAM_OUT
+    cmd = [shutil.which("g++") or "g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", BAM_OUT, BAM_SRC, "-lz", "-pthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return BAM_OUT
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_bam(force=True, verbose=True)

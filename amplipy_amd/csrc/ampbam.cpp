@@ -1,0 +1,396 @@
+// ampbam.cpp -- BAM/BGZF decode into the packed read batch and re-encode of trimmed records.
+// See include/ampbam.h for what this replaces in the reference (pysam, AmpliPy.py:296-356, :896-911).
+// Host only: zlib + std::thread.  The whole file is inflated into one buffer (an amplicon BAM at
+// 100k x is a few GB; the GPU box has > 250 GB of RAM), so records are addressable by number and
+// the writer can copy the unchanged parts of a record straight from the input image.
+#include "../../include/ampbam.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+inline void put16(uint8_t *p, uint16_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+
+int pick_threads(int n) {
+    if (n > 0) return std::min(n, 64);
+    unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+template <class F>
+void parallel_for(int n_threads, int64_t n_items, F &&fn) {   // fn(item) ; dynamic hand-out in chunks
+    if (n_items <= 0) return;
+    const int nt = (int)std::min<int64_t>(n_threads, n_items);
+    if (nt <= 1) { for (int64_t i = 0; i < n_items; ++i) fn(i); return; }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n_items) break; fn(i); } });
+    for (auto &x : th) x.join();
+}
+
+// SAMv1 5.3: bin of the 0-based half-open interval [beg, end)
+inline uint16_t reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (uint16_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint16_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint16_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint16_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint16_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
+
+}  // namespace
+
+struct ampbam_file {
+    std::vector<uint8_t> data;              // the inflated stream
+    size_t text_off = 0, text_len = 0;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_lens;
+    std::vector<uint64_t> rec_off;          // offset of every record's block_size field (+ end sentinel)
+    int n_threads = 1;
+    std::string err;
+    // decode outputs (reused)
+    std::vector<int32_t> pos, tlen;
+    std::vector<uint16_t> flag;
+    std::vector<uint32_t> lseq, cig;
+    std::vector<uint64_t> cig_off, seq_off;
+    std::vector<uint8_t> seq, qual;
+    std::vector<int64_t> src_index;
+};
+
+struct ampbam_writer {
+    FILE *fp = nullptr;
+    int level = -1, n_threads = 1;
+    std::vector<uint8_t> pend;              // uncompressed bytes not yet written
+    std::string err;
+};
+
+extern "C" {
+
+int ampbam_version(void) { return 1; }
+
+const char *ampbam_strerror(int rc) {
+    switch (rc) {
+        case AMPBAM_OK: return "ok";
+        case AMPBAM_EINVAL: return "invalid argument";
+        case AMPBAM_EIO: return "I/O error";
+        case AMPBAM_EFORMAT: return "not a valid BGZF/BAM stream";
+        case AMPBAM_ENOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char *ampbam_last_error(const ampbam_file *f) { return f ? f->err.c_str() : ""; }
+
+void ampbam_close(ampbam_file *f) { delete f; }
+
+int ampbam_open(const char *path, int n_threads, ampbam_file **out) {
+    if (!path || !out) return AMPBAM_EINVAL;
+    *out = nullptr;
+    ampbam_file *f = new (std::nothrow) ampbam_file();
+    if (!f) return AMPBAM_ENOMEM;
+    f->n_threads = pick_threads(n_threads);
+    auto fail = [&](int rc, const char *msg) { (void)msg; delete f; return rc; };
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return fail(AMPBAM_EIO, "open");
+    std::vector<uint8_t> raw;
+    try {
+        if (std::fseek(fp, 0, SEEK_END) != 0) { std::fclose(fp); return fail(AMPBAM_EIO, "seek"); }
+        const long sz = std::ftell(fp);
+        if (sz < 0) { std::fclose(fp); return fail(AMPBAM_EIO, "tell"); }
+        std::rewind(fp);
+        raw.resize((size_t)sz);
+        if (sz && std::fread(raw.data(), 1, (size_t)sz, fp) != (size_t)sz) { std::fclose(fp); return fail(AMPBAM_EIO, "read"); }
+    } catch (const std::bad_alloc &) { std::fclose(fp); return fail(AMPBAM_ENOMEM, "alloc"); }
+    std::fclose(fp);
+
+    // ---- BGZF block table (serial hop over the headers) -----------------------------------
+    std::vector<Block> blocks;
+    size_t p = 0, total = 0;
+    while (p < raw.size()) {
+        if (raw.size() - p < 18 || raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) return fail(AMPBAM_EFORMAT, "gzip header");
+        const size_t xlen = le16(&raw[p + 10]);
+        if (raw.size() - p < 12 + xlen) return fail(AMPBAM_EFORMAT, "extra field");
+        size_t bsize = 0, q = p + 12;
+        const size_t xend = p + 12 + xlen;
+        while (q + 4 <= xend) {
+            const size_t slen = le16(&raw[q + 2]);
+            if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)le16(&raw[q + 4]) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || raw.size() - p < bsize) return fail(AMPBAM_EFORMAT, "block size");
+        Block b;
+        b.in_off = p + 12 + xlen; b.in_len = bsize - 12 - xlen - 8;
+        b.crc = le32(&raw[p + bsize - 8]); b.out_len = le32(&raw[p + bsize - 4]);
+        b.out_off = total;
+        if (b.out_len > 65536) return fail(AMPBAM_EFORMAT, "ISIZE");
+        total += b.out_len;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    try { f->data.resize(total + 16); } catch (const std::bad_alloc &) { return fail(AMPBAM_ENOMEM, "alloc"); }
+
+    // ---- inflate, in parallel ---------------------------------------------------------------
+    std::atomic<int> bad{0};
+    const int64_t nb = (int64_t)blocks.size(), grain = 16;
+    parallel_for(f->n_threads, (nb + grain - 1) / grain, [&](int64_t c) {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+        for (int64_t k = c * grain; k < std::min(nb, (c + 1) * grain); ++k) {
+            const Block &b = blocks[(size_t)k];
+            if (b.out_len == 0) continue;
+            inflateReset(&zs);
+            zs.next_in = const_cast<Bytef *>(raw.data() + b.in_off); zs.avail_in = (uInt)b.in_len;
+            zs.next_out = f->data.data() + b.out_off; zs.avail_out = (uInt)b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), f->data.data() + b.out_off, (uInt)b.out_len) != b.crc) { bad = 1; break; }
+        }
+        inflateEnd(&zs);
+    });
+    if (bad) return fail(AMPBAM_EFORMAT, "inflate / CRC");
+    raw.clear(); raw.shrink_to_fit();
+
+    // ---- BAM header ----------------------------------------------------------------------------
+    const uint8_t *d = f->data.data();
+    size_t o = 0;
+    if (total < 12 || std::memcmp(d, "BAM\1", 4) != 0) return fail(AMPBAM_EFORMAT, "BAM magic");
+    const size_t l_text = le32(d + 4);
+    if (total < 12 + l_text) return fail(AMPBAM_EFORMAT, "header text");
+    f->text_off = 8; f->text_len = l_text;
+    o = 8 + l_text;
+    const int32_t n_ref = (int32_t)le32(d + o); o += 4;
+    if (n_ref < 0) return fail(AMPBAM_EFORMAT, "n_ref");
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (total < o + 4) return fail(AMPBAM_EFORMAT, "reference");
+        const size_t l_name = le32(d + o); o += 4;
+        if (l_name == 0 || total < o + l_name + 4) return fail(AMPBAM_EFORMAT, "reference");
+        f->ref_names.emplace_back((const char *)(d + o), l_name - 1); o += l_name;
+        f->ref_lens.push_back((int32_t)le32(d + o)); o += 4;
+    }
+    // ---- record index ------------------------------------------------------------------------
+    while (o < total) {
+        if (total - o < 4) return fail(AMPBAM_EFORMAT, "record size");
+        const size_t bs = le32(d + o);
+        if (bs < 32 || total - o - 4 < bs) return fail(AMPBAM_EFORMAT, "record");
+        f->rec_off.push_back(o);
+        o += 4 + bs;
+    }
+    f->rec_off.push_back(o);
+    *out = f;
+    return AMPBAM_OK;
+}
+
+int64_t ampbam_n_records(const ampbam_file *f) { return f ? (int64_t)f->rec_off.size() - 1 : 0; }
+
+int ampbam_header_text(const ampbam_file *f, const char **text, int64_t *len) {
+    if (!f || !text || !len) return AMPBAM_EINVAL;
+    *text = (const char *)f->data.data() + f->text_off;
+    size_t n = f->text_len;
+    while (n && (*text)[n - 1] == '\0') --n;      // some writers NUL-pad the text
+    *len = (int64_t)n;
+    return AMPBAM_OK;
+}
+
+int32_t ampbam_n_refs(const ampbam_file *f) { return f ? (int32_t)f->ref_names.size() : 0; }
+
+int ampbam_ref(const ampbam_file *f, int32_t i, const char **name, int32_t *length) {
+    if (!f || i < 0 || i >= (int32_t)f->ref_names.size()) return AMPBAM_EINVAL;
+    if (name) *name = f->ref_names[(size_t)i].c_str();
+    if (length) *length = f->ref_lens[(size_t)i];
+    return AMPBAM_OK;
+}
+
+int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *out) {
+    if (!f || !out || first < 0 || count < 0 || first + count > ampbam_n_records(f)) return AMPBAM_EINVAL;
+    const uint8_t *d = f->data.data();
+    // pass 1 (serial, fixed fields only): which records are rows, and where their variable parts go
+    try {
+        f->src_index.clear(); f->cig_off.assign(1, 0); f->seq_off.assign(1, 0);
+        f->src_index.reserve((size_t)count); f->cig_off.reserve((size_t)count + 1); f->seq_off.reserve((size_t)count + 1);
+        uint64_t co = 0, so = 0;
+        for (int64_t r = first; r < first + count; ++r) {
+            const uint8_t *c = d + f->rec_off[(size_t)r] + 4;
+            const uint32_t n_cig = le16(c + 12), flag = le16(c + 14), l_seq = le32(c + 16), l_name = c[8];
+            const uint64_t bs = f->rec_off[(size_t)r + 1] - f->rec_off[(size_t)r] - 4;
+            if (32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) { f->err = "record " + std::to_string(r) + " is shorter than its fields"; return AMPBAM_EFORMAT; }
+            if ((flag & 4u) || n_cig == 0) continue;                                    // AmpliPy.py:902
+            f->src_index.push_back(r);
+            co += n_cig; so += ((uint64_t)l_seq + 7) & ~7ull;
+            f->cig_off.push_back(co); f->seq_off.push_back(so);
+        }
+        const size_t n = f->src_index.size();
+        f->pos.resize(n); f->tlen.resize(n); f->flag.resize(n); f->lseq.resize(n);
+        f->cig.resize((size_t)co + 4);
+        f->seq.assign((size_t)(so / 2) + 16, 0); f->qual.assign((size_t)so + 16, 0);
+    } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
+    // pass 2 (parallel): copy
+    const int64_t n = (int64_t)f->src_index.size(), grain = 4096;
+    parallel_for(f->n_threads, (n + grain - 1) / grain, [&](int64_t ch) {
+        for (int64_t i = ch * grain; i < std::min(n, (ch + 1) * grain); ++i) {
+            const uint8_t *c = d + f->rec_off[(size_t)f->src_index[(size_t)i]] + 4;
+            const uint32_t l_name = c[8], n_cig = le16(c + 12), l_seq = le32(c + 16);
+            f->pos[(size_t)i] = (int32_t)le32(c + 4);
+            f->flag[(size_t)i] = le16(c + 14);
+            f->lseq[(size_t)i] = l_seq;
+            f->tlen[(size_t)i] = (int32_t)le32(c + 28);
+            const uint8_t *v = c + 32 + l_name;
+            std::memcpy(&f->cig[(size_t)f->cig_off[(size_t)i]], v, 4ull * n_cig);       // little-endian host
+            v += 4ull * n_cig;
+            const uint64_t so = f->seq_off[(size_t)i];
+            std::memcpy(&f->seq[(size_t)(so / 2)], v, (l_seq + 1) / 2);
+            if (l_seq & 1) f->seq[(size_t)(so / 2) + l_seq / 2] &= 0xF0;               // spare nibble is zero in the batch
+            v += (l_seq + 1) / 2;
+            std::memcpy(&f->qual[(size_t)so], v, l_seq);
+        }
+    });
+    out->n_reads = n;
+    out->pos = f->pos.data(); out->flag = f->flag.data(); out->tlen = f->tlen.data(); out->lseq = f->lseq.data();
+    out->cig_off = f->cig_off.data(); out->cig = f->cig.data(); out->seq_off = f->seq_off.data();
+    out->seq = f->seq.data(); out->qual = f->qual.data(); out->src_index = f->src_index.data();
+    out->n_cig = (int64_t)f->cig_off.back(); out->n_bases = (int64_t)f->seq_off.back();
+    out->n_skipped = count - n;
+    return AMPBAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// writer
+// ---------------------------------------------------------------------------------------------
+static int flush_blocks(ampbam_writer *w, bool all) {
+    const size_t BS = 0xFF00;
+    const size_t nfull = w->pend.size() / BS, nblk = nfull + ((all && w->pend.size() % BS) ? 1 : 0);
+    if (nblk == 0) return AMPBAM_OK;
+    std::vector<std::vector<uint8_t>> outb(nblk);
+    std::atomic<int> bad{0};
+    parallel_for(w->n_threads, (int64_t)nblk, [&](int64_t k) {
+        const size_t off = (size_t)k * BS, len = std::min(BS, w->pend.size() - off);
+        std::vector<uint8_t> &o = outb[(size_t)k];
+        o.resize(18 + compressBound((uLong)len) + 8);
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+        zs.next_in = w->pend.data() + off; zs.avail_in = (uInt)len;
+        zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 18 - 8);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END || clen + 26 > 65536) { bad = 1; return; }
+        const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        std::memcpy(o.data(), hdr, 16);
+        put16(o.data() + 16, (uint16_t)(clen + 25));
+        put32(o.data() + 18 + clen, (uint32_t)crc32(crc32(0L, Z_NULL, 0), w->pend.data() + off, (uInt)len));
+        put32(o.data() + 18 + clen + 4, (uint32_t)len);
+        o.resize(18 + clen + 8);
+    });
+    if (bad) return AMPBAM_EIO;
+    for (auto &o : outb)
+        if (std::fwrite(o.data(), 1, o.size(), w->fp) != o.size()) return AMPBAM_EIO;
+    const size_t used = std::min(w->pend.size(), nblk * BS);
+    w->pend.erase(w->pend.begin(), w->pend.begin() + (ptrdiff_t)used);
+    return AMPBAM_OK;
+}
+
+int ampbam_writer_open(const char *path, const char *header_text, int64_t header_len, const ampbam_file *like,
+                       int level, int n_threads, ampbam_writer **out) {
+    if (!path || !out || header_len < 0 || (header_len && !header_text) || !like || level < -1 || level > 9) return AMPBAM_EINVAL;
+    *out = nullptr;
+    ampbam_writer *w = new (std::nothrow) ampbam_writer();
+    if (!w) return AMPBAM_ENOMEM;
+    w->level = level; w->n_threads = pick_threads(n_threads);
+    w->fp = std::fopen(path, "wb");
+    if (!w->fp) { delete w; return AMPBAM_EIO; }
+    std::vector<uint8_t> &b = w->pend;
+    b.insert(b.end(), {'B', 'A', 'M', 1});
+    uint8_t t[4];
+    put32(t, (uint32_t)header_len); b.insert(b.end(), t, t + 4);
+    b.insert(b.end(), (const uint8_t *)header_text, (const uint8_t *)header_text + header_len);
+    put32(t, (uint32_t)like->ref_names.size()); b.insert(b.end(), t, t + 4);
+    for (size_t r = 0; r < like->ref_names.size(); ++r) {
+        const std::string &nm = like->ref_names[r];
+        put32(t, (uint32_t)nm.size() + 1); b.insert(b.end(), t, t + 4);
+        b.insert(b.end(), nm.begin(), nm.end()); b.push_back(0);
+        put32(t, (uint32_t)like->ref_lens[r]); b.insert(b.end(), t, t + 4);
+    }
+    *out = w;
+    return AMPBAM_OK;
+}
+
+int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, const int64_t *src_index,
+                      const uint8_t *keep, const int32_t *new_pos, const uint32_t *new_ncig,
+                      const uint64_t *new_cig_off, const uint32_t *new_cig) {
+    if (!w || !src || n_rows < 0 || (n_rows && (!src_index || !keep || !new_pos || !new_ncig || !new_cig_off || !new_cig))) return AMPBAM_EINVAL;
+    const uint8_t *d = src->data.data();
+    const int64_t n_rec = ampbam_n_records(src);
+    // sizes first, so that rows can be encoded in parallel straight into the pending buffer
+    std::vector<uint64_t> off((size_t)n_rows + 1, 0);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        uint64_t sz = 0;
+        if (keep[i]) {
+            const int64_t r = src_index[i];
+            if (r < 0 || r >= n_rec || new_ncig[i] > 65535u) return AMPBAM_EINVAL;
+            const uint8_t *c = d + src->rec_off[(size_t)r] + 4;
+            const uint64_t bs = src->rec_off[(size_t)r + 1] - src->rec_off[(size_t)r] - 4;
+            sz = 4 + bs - 4ull * le16(c + 12) + 4ull * new_ncig[i];
+        }
+        off[(size_t)i + 1] = off[(size_t)i] + sz;
+    }
+    const size_t base = w->pend.size();
+    try { w->pend.resize(base + (size_t)off[(size_t)n_rows]); } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
+    uint8_t *ob = w->pend.data() + base;
+    const int64_t grain = 4096;
+    parallel_for(w->n_threads, (n_rows + grain - 1) / grain, [&](int64_t ch) {
+        for (int64_t i = ch * grain; i < std::min(n_rows, (ch + 1) * grain); ++i) {
+            if (!keep[i]) continue;
+            const int64_t r = src_index[i];
+            const uint8_t *c = d + src->rec_off[(size_t)r] + 4;
+            const uint64_t bs = src->rec_off[(size_t)r + 1] - src->rec_off[(size_t)r] - 4;
+            const uint32_t l_name = c[8], old_n = le16(c + 12), nn = new_ncig[i];
+            uint8_t *o = ob + off[(size_t)i];
+            put32(o, (uint32_t)(bs - 4ull * old_n + 4ull * nn));
+            uint8_t *q = o + 4;
+            std::memcpy(q, c, 32 + l_name);                                  // fixed fields + name
+            const uint32_t *cg = new_cig + new_cig_off[i];
+            int64_t rlen = 0;
+            for (uint32_t k = 0; k < nn; ++k) {
+                const uint32_t op = cg[k] & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cg[k] >> 4;
+            }
+            const int64_t pos = new_pos[i], end = pos + (rlen ? rlen : 1);
+            put32(q + 4, (uint32_t)new_pos[i]);
+            put16(q + 10, reg2bin(pos > 0 ? pos : 0, end > 1 ? end : 1));
+            put16(q + 12, (uint16_t)nn);
+            std::memcpy(q + 32 + l_name, cg, 4ull * nn);
+            const uint64_t tail_from = 32ull + l_name + 4ull * old_n;          // bases, qualities, aux
+            std::memcpy(q + 32 + l_name + 4ull * nn, c + tail_from, bs - tail_from);
+        }
+    });
+    return flush_blocks(w, false);
+}
+
+int ampbam_writer_close(ampbam_writer *w) {
+    if (!w) return AMPBAM_EINVAL;
+    int rc = flush_blocks(w, true);
+    if (rc == AMPBAM_OK && std::fwrite(BGZF_EOF, 1, sizeof(BGZF_EOF), w->fp) != sizeof(BGZF_EOF)) rc = AMPBAM_EIO;
+    if (std::fclose(w->fp) != 0 && rc == AMPBAM_OK) rc = AMPBAM_EIO;
+    delete w;
+    return rc;
+}
+
+}  // extern "C"

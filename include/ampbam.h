@@ -1,0 +1,93 @@
+/* ampbam.h -- host-side BAM/BGZF decode into the packed read batch of amplihip.h, and re-encode
+ * of trimmed records.  Plain C ABI, no GPU, no torch types.
+ *
+ * Replaces, for BAM files, what AmpliPy v0.0.2 gets from pysam (a dependency that is not part of
+ * /root/reference: pysam 0.17.0 / htslib 1.13, requirements.txt:1):
+ *   pysam.AlignmentFile(fn, 'rb') + iteration           AmpliPy.py:296-324, :896
+ *   the skip rule `is_unmapped or cigartuples is None`  AmpliPy.py:902
+ *   pysam.AlignmentFile(fn, 'wb', header=...) / write   AmpliPy.py:326-356, :911
+ * The format is restated from the SAM/BAM specification (SAMv1 section 4): BGZF = concatenated gzip
+ * members of <= 64 KiB with a `BC` extra subfield holding the block size; a BAM record is
+ * block_size, 32 bytes of fixed fields, read name, uint32 CIGAR (len<<4|op), 4-bit bases (high
+ * nibble first), qualities (0xFF... = absent), auxiliary fields.
+ *
+ * Every function returns 0 or a negative ampbam_rc; nothing throws across the ABI.  A handle is
+ * not thread-safe; the library uses its own worker threads inside a call.
+ */
+#ifndef AMPBAM_H
+#define AMPBAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ampbam_file ampbam_file;       /* a BAM file, fully inflated in host memory */
+typedef struct ampbam_writer ampbam_writer;
+
+enum ampbam_rc {
+    AMPBAM_OK = 0,
+    AMPBAM_EINVAL = -1,   /* bad argument */
+    AMPBAM_EIO = -2,      /* open / read / write failed */
+    AMPBAM_EFORMAT = -3,  /* not BGZF / not BAM / truncated / CRC mismatch */
+    AMPBAM_ENOMEM = -4
+};
+
+int ampbam_version(void);
+const char *ampbam_strerror(int rc);
+
+/* ---- reading ---------------------------------------------------------------------------- */
+/* Reads `path`, inflates all BGZF blocks with `n_threads` workers (<= 0: one per available CPU,
+ * at most 16), checks each block's CRC32, parses the header and indexes the records. */
+int ampbam_open(const char *path, int n_threads, ampbam_file **out);
+void ampbam_close(ampbam_file *f);
+const char *ampbam_last_error(const ampbam_file *f);
+
+int64_t ampbam_n_records(const ampbam_file *f);
+/* SAM header text (not NUL-terminated; *len bytes) and the reference dictionary. */
+int ampbam_header_text(const ampbam_file *f, const char **text, int64_t *len);
+int32_t ampbam_n_refs(const ampbam_file *f);
+int ampbam_ref(const ampbam_file *f, int32_t i, const char **name, int32_t *length);
+
+/* Records [first, first+count) decoded into the packed structure-of-arrays batch that
+ * amp_process_batch takes (same field meaning as struct amp_reads in amplihip.h).  Rows are the
+ * records the reference's loop does not skip (mapped, at least one CIGAR op; AmpliPy.py:902), in
+ * file order; src_index[i] is the record number of row i.  The arrays belong to `f` and stay valid
+ * until the next ampbam_decode / ampbam_close on it. */
+typedef struct ampbam_batch {
+    int64_t n_reads;
+    const int32_t *pos;        /* 0-based leftmost reference position */
+    const uint16_t *flag;
+    const int32_t *tlen;
+    const uint32_t *lseq;
+    const uint64_t *cig_off;   /* [n_reads+1] into cig */
+    const uint32_t *cig;       /* len<<4|op */
+    const uint64_t *seq_off;   /* [n_reads+1], in bases, every read starts on a multiple of 8 */
+    const uint8_t *seq;        /* 4-bit codes, high nibble first; seq_off/2 bytes into it */
+    const uint8_t *qual;       /* one byte per base at seq_off; first byte 0xFF = no qualities */
+    const int64_t *src_index;  /* [n_reads] record numbers */
+    int64_t n_cig, n_bases;    /* totals: cig_off[n_reads], seq_off[n_reads]; seq and qual carry 16 spare bytes */
+    int64_t n_skipped;         /* records of the range left out by the skip rule */
+} ampbam_batch;
+int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *out);
+
+/* ---- writing ---------------------------------------------------------------------------- */
+/* A new BAM file with the given SAM header text and the reference dictionary of `like`
+ * (AmpliPy.py:343-346 copies the input's references).  level = zlib level 0..9 (-1: default). */
+int ampbam_writer_open(const char *path, const char *header_text, int64_t header_len, const ampbam_file *like,
+                       int level, int n_threads, ampbam_writer **out);
+/* Appends rows of a decoded batch whose keep[i] != 0, re-encoded with a new position and CIGAR:
+ * row i of the batch is record src_index[i] of `src`; its new CIGAR is new_ncig[i] words at
+ * new_cig + new_cig_off[i].  block_size, bin (reg2bin of [pos, end)), n_cigar_op and pos change,
+ * everything else (name, flag, mapq, mate fields, bases, qualities, aux) is copied. */
+int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, const int64_t *src_index,
+                      const uint8_t *keep, const int32_t *new_pos, const uint32_t *new_ncig,
+                      const uint64_t *new_cig_off, const uint32_t *new_cig);
+/* Flushes, writes the BGZF end-of-file block, closes the file and frees the writer. */
+int ampbam_writer_close(ampbam_writer *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

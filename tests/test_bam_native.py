@@ -1,0 +1,119 @@
+"""libampbam (include/ampbam.h): the native BAM decode / re-encode against the Python codec of
+bamio.py on the same files.  No GPU needed."""
+import ctypes as C
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from amplipy_amd import bam_native, bamio, synth
+from amplipy_amd.batch import ReadBatch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_bam(path, n=700, seed=11, with_oddities=True):
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    segs = synth.make_mixed_segments(g, amps, n, seed=seed)
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:SYN_REF\tLN:%d\n@PG\tID:sim\tPN:sim\tVN:1\tCL:sim x\n" % g.size
+    hdr = bamio.Header(text, [("SYN_REF", int(g.size))])
+    recs = []
+    for i, s in enumerate(segs):
+        recs.append(bamio.Rec("r%d" % i, s.flag, 0, s.reference_start, 60, s.cigartuples, 0, s.reference_start, s.template_length,
+                              s.query_sequence, bytes(s.query_qualities), aux_sam=["NM:i:%d" % (i % 7), "XZ:Z:abc"]))
+    if with_oddities:
+        recs.insert(5, bamio.Rec("unmapped", 4, -1, -1, 0, None, -1, -1, 0, "ACGTN", bytes([30] * 5)))          # skipped (A:902)
+        recs.insert(9, bamio.Rec("nocigar", 0, 0, 100, 0, None, -1, -1, 0, "ACGT", bytes([30] * 4)))               # skipped: no CIGAR
+        recs.insert(12, bamio.Rec("noqual", 0, 0, 200, 60, [(0, 7)], -1, -1, 0, "ACGTACG", None))                   # QUAL '*'
+        recs.insert(15, bamio.Rec("odd", 16, 0, 300, 60, [(4, 2), (0, 9)], -1, -1, 0, "ACGTACGTANN"[:11], bytes(range(11))))
+    w = bamio.AlignmentWriter(path, "wb", hdr)
+    for r in recs:
+        w.write(r)
+    w.close()
+    return hdr, recs
+
+
+def test_header_declares_exactly_the_exports():
+    L = bam_native.load()
+    decl = re.findall(r"\b(ampbam_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "ampbam.h")).read())
+    assert sorted(set(decl)) == sorted(bam_native.EXPORTS)
+    assert L.ampbam_version() == 1
+
+
+def test_decode_matches_python_codec(tmp_path):
+    bam = str(tmp_path / "a.bam")
+    hdr, recs = _make_bam(bam)
+    f = bam_native.BamFile(bam, threads=3)
+    assert f.n_records == len(recs) and f.header_text == hdr.text and f.references == hdr.refs
+    kept = [(i, r) for i, r in enumerate(recs) if not (r.flag & 4) and r.cigar is not None]
+    want = ReadBatch.from_segments([r.to_segment() for _, r in kept])
+    got, skipped = f.decode(0, f.n_records, copy=True)
+    assert skipped == len(recs) - len(kept) == 2
+    assert got.src_index.tolist() == [i for i, _ in kept]
+    for name in ("pos", "flag", "tlen", "lseq", "cig_off", "cig", "seq_off", "seq", "qual"):
+        assert np.array_equal(getattr(got, name), getattr(want, name)), name
+    # record ranges: any split gives the same rows
+    a, _ = f.decode(0, 10, copy=True)
+    b, _ = f.decode(10, f.n_records - 10, copy=True)
+    assert np.array_equal(np.concatenate([a.pos, b.pos]), want.pos) and a.n + b.n == want.n
+    assert np.array_equal(np.concatenate([a.cig, b.cig]), want.cig)
+    assert np.array_equal(np.concatenate([a.src_index, b.src_index]), got.src_index)
+    f.close()
+
+
+def test_reencode_matches_python_writer(tmp_path):
+    bam = str(tmp_path / "a.bam"); out_n = str(tmp_path / "n.bam"); out_p = str(tmp_path / "p.bam")
+    hdr, recs = _make_bam(bam)
+    f = bam_native.BamFile(bam, threads=2)
+    batch, _ = f.decode(0, f.n_records, copy=True)
+    rng = np.random.default_rng(3)
+    n = batch.n
+    keep = (rng.random(n) < 0.8).astype(np.uint8)
+    new_pos = batch.pos + rng.integers(0, 30, n).astype(np.int32)
+    # new CIGARs in slots of old length + 3, like the device writes them
+    slot_off = (batch.cig_off[:-1] + 3 * np.arange(n, dtype=np.uint64)).astype(np.uint64)
+    new_cig = np.zeros(int(batch.cig.size) + 3 * n, np.uint32)
+    new_ncig = np.zeros(n, np.uint32)
+    cigars = []
+    for i in range(n):
+        k = int(rng.integers(1, 4))
+        ops = [(int(rng.choice([0, 1, 2, 4, 7, 8])), int(rng.integers(1, 40))) for _ in range(k)]
+        cigars.append(ops); new_ncig[i] = k
+        new_cig[int(slot_off[i]):int(slot_off[i]) + k] = [(ln << 4) | op for op, ln in ops]
+    hdr2 = hdr.with_amplipy_pg("0.0.2", "amplipy trim")
+    w = bam_native.BamWriter(out_n, hdr2.text, f, threads=2)
+    half = n // 2                                                   # two calls, like two batches
+    w.write_rows(batch.src_index[:half], keep[:half], new_pos[:half], new_ncig[:half], slot_off[:half], new_cig)
+    w.write_rows(batch.src_index[half:], keep[half:], new_pos[half:], new_ncig[half:], slot_off[half:], new_cig)
+    w.close()
+    pw = bamio.AlignmentWriter(out_p, "wb", hdr2)
+    rd = bamio.AlignmentReader(bam, "rb")
+    all_recs = list(rd)
+    for i in range(n):
+        if keep[i]:
+            pw.write(all_recs[int(batch.src_index[i])], pos=int(new_pos[i]), cigar=cigars[i])
+    pw.close()
+    raw_n = gzip.decompress(open(out_n, "rb").read()); raw_p = gzip.decompress(open(out_p, "rb").read())
+    assert raw_n == raw_p                                           # byte-identical BAM streams
+    assert open(out_n, "rb").read().endswith(bamio.BGZF_EOF)
+    back = list(bamio.AlignmentReader(out_n, "rb"))
+    assert len(back) == int(keep.sum())
+    f.close()
+
+
+def test_bad_input_is_refused(tmp_path):
+    p = str(tmp_path / "x.bam")
+    open(p, "wb").write(b"not a bam at all")
+    with pytest.raises(bam_native.AmpBamError):
+        bam_native.BamFile(p)
+    bam = str(tmp_path / "a.bam")
+    _make_bam(bam, n=50, with_oddities=False)
+    raw = bytearray(open(bam, "rb").read())
+    raw[40] ^= 0x55                                                  # corrupt the first block's payload
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(bam_native.AmpBamError):
+        bam_native.BamFile(p)
+    with pytest.raises(bam_native.AmpBamError):
+        bam_native.BamFile(str(tmp_path / "missing.bam"))

@@ -216,7 +216,7 @@ def test_device_double_division_is_python_division(runner):
 
 
 @pytest.mark.parametrize("ext", ["sam", "bam"])
-def test_end_to_end_aio_cli(tmp_path, ext, runner):
+def test_end_to_end_aio_cli(tmp_path, ext, runner, monkeypatch):
     """run_amplipy 'aio' on files: trimmed reads, VCF and consensus agree with the golden pileup."""
     if runner.variant != 2:
         pytest.skip("the CLI always uses the default kernel")
@@ -258,3 +258,15 @@ def test_end_to_end_aio_cli(tmp_path, ext, runner):
         assert (f[0], int(f[1]), f[3], f[4], f[6]) == ("SYN_REF", c["pos"] + 1, v["ref"], ",".join(v["alts"]), "PASS")
         assert (int(info["DP"]), int(info["REF_DP"]), info["ALT_DP"], info["ALT_FREQ"]) == (v["DP"], v["REF_DP"], v["ALT_DP"], v["ALT_FREQ"])
         assert info["REF_FREQ"] == "%g" % float.fromhex(v["REF_FREQ"]) and f[9] == "/".join(str(x) for x in v["GT"])
+    if ext == "bam":
+        # the run above went through libampbam (BAM in, BAM out); the Python codec must give the same stream
+        import gzip
+        out_t2 = str(tmp_path / "t2.bam"); out_v2 = str(tmp_path / "v2.vcf"); out_c2 = str(tmp_path / "c2.fas")
+        monkeypatch.setenv("AMPLIPY_PYTHON_BAM", "1")
+        monkeypatch.setattr("sys.argv", list(__import__("sys").argv))
+        amplipy.main(["aio", "-i", inp, "-p", str(bed), "-r", str(ref), "-ot", out_t2, "-ov", out_v2, "-oc", out_c2,
+                      "-mq", str(p["min_quality"]), "-s", str(p["window"]), "-ml", str(p["min_length"]),
+                      "-mdc", str(p["min_depth_consensus"]), "-mfc", str(p["min_freq_consensus"]),
+                      "-mdv", str(p["min_depth_variants"]), "-mfv", str(p["min_freq_variants"])])
+        assert gzip.decompress(open(out_t, "rb").read()) == gzip.decompress(open(out_t2, "rb").read())
+        assert open(out_v).read() == open(out_v2).read() and open(out_c).read() == open(out_c2).read()
