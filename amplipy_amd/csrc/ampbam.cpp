@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -55,10 +56,32 @@ const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06,
 
 struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 
+// byte buffer that is NOT zero-filled on allocation (the inflated image is tens of MB to GB)
+struct Bytes {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    Bytes() = default;
+    Bytes(const Bytes &) = delete;
+    Bytes &operator=(const Bytes &) = delete;
+    ~Bytes() { std::free(p); }
+    bool resize(size_t m) {
+        if (m > cap) {
+            uint8_t *q = (uint8_t *)std::realloc(p, m);
+            if (!q) return false;
+            p = q; cap = m;
+        }
+        n = m;
+        return true;
+    }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
+
 }  // namespace
 
 struct ampbam_file {
-    std::vector<uint8_t> data;              // the inflated stream
+    Bytes data;                             // the inflated stream
     size_t text_off = 0, text_len = 0;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
@@ -70,7 +93,7 @@ struct ampbam_file {
     std::vector<uint16_t> flag;
     std::vector<uint32_t> lseq, cig;
     std::vector<uint64_t> cig_off, seq_off;
-    std::vector<uint8_t> seq, qual;
+    Bytes seq, qual;
     std::vector<int64_t> src_index;
 };
 
@@ -144,7 +167,8 @@ int ampbam_open(const char *path, int n_threads, ampbam_file **out) {
         blocks.push_back(b);
         p += bsize;
     }
-    try { f->data.resize(total + 16); } catch (const std::bad_alloc &) { return fail(AMPBAM_ENOMEM, "alloc"); }
+    if (!f->data.resize(total + 16)) return fail(AMPBAM_ENOMEM, "alloc");
+    std::memset(f->data.data() + total, 0, 16);
 
     // ---- inflate, in parallel ---------------------------------------------------------------
     std::atomic<int> bad{0};
@@ -239,7 +263,8 @@ int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *ou
         const size_t n = f->src_index.size();
         f->pos.resize(n); f->tlen.resize(n); f->flag.resize(n); f->lseq.resize(n);
         f->cig.resize((size_t)co + 4);
-        f->seq.assign((size_t)(so / 2) + 16, 0); f->qual.assign((size_t)so + 16, 0);
+        if (!f->seq.resize((size_t)(so / 2) + 16) || !f->qual.resize((size_t)so + 16)) return AMPBAM_ENOMEM;
+        std::memset(f->seq.data() + so / 2, 0, 16); std::memset(f->qual.data() + so, 0, 16);
     } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
     // pass 2 (parallel): copy
     const int64_t n = (int64_t)f->src_index.size(), grain = 4096;
@@ -255,10 +280,14 @@ int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *ou
             std::memcpy(&f->cig[(size_t)f->cig_off[(size_t)i]], v, 4ull * n_cig);       // little-endian host
             v += 4ull * n_cig;
             const uint64_t so = f->seq_off[(size_t)i];
-            std::memcpy(&f->seq[(size_t)(so / 2)], v, (l_seq + 1) / 2);
-            if (l_seq & 1) f->seq[(size_t)(so / 2) + l_seq / 2] &= 0xF0;               // spare nibble is zero in the batch
+            const uint64_t padded = f->seq_off[(size_t)i + 1] - so;                       // bases, multiple of 8
+            uint8_t *sq = f->seq.data() + so / 2, *ql = f->qual.data() + so;
+            std::memcpy(sq, v, (l_seq + 1) / 2);
+            if (l_seq & 1) sq[l_seq / 2] &= 0xF0;                                      // spare nibble and padding are zero in the batch
+            std::memset(sq + (l_seq + 1) / 2, 0, (size_t)(padded / 2 - (l_seq + 1) / 2));
             v += (l_seq + 1) / 2;
-            std::memcpy(&f->qual[(size_t)so], v, l_seq);
+            std::memcpy(ql, v, l_seq);
+            std::memset(ql + l_seq, 0, (size_t)(padded - l_seq));
         }
     });
     out->n_reads = n;
