@@ -270,3 +270,108 @@ def test_end_to_end_aio_cli(tmp_path, ext, runner, monkeypatch):
                       "-mdv", str(p["min_depth_variants"]), "-mfv", str(p["min_freq_variants"])])
         assert gzip.decompress(open(out_t, "rb").read()) == gzip.decompress(open(out_t2, "rb").read())
         assert open(out_v).read() == open(out_v2).read() and open(out_c).read() == open(out_c2).read()
+
+
+# ---- layouts the kernels do not favour: results must not depend on them ------------------------
+def _long_read_segments(rng, n, ref_len, max_len, max_ops):
+    """Regular CIGARs with many ops (M/=/X alternating with I/D/N), optional clips, lengths up to max_len."""
+    from amplipy_amd.segment import Segment
+    segs = []
+    for _ in range(n):
+        n_body = int(rng.integers(1, max_ops // 2 + 1)) * 2 - 1
+        L_target = int(rng.integers(50, max_len + 1))
+        ops, q = [], 0
+        if rng.random() < 0.4:
+            k = int(rng.integers(1, 30)); ops.append((4, k)); q += k
+        per = max(1, (L_target - q) // ((n_body + 1) // 2))
+        for b in range(n_body):
+            if b % 2 == 0:
+                k = int(rng.integers(1, per + 1)); ops.append((int(rng.choice([0, 0, 7, 8])), k)); q += k
+            else:
+                op = int(rng.choice([1, 2, 3])); k = int(rng.integers(1, 9)); ops.append((op, k)); q += k if op == 1 else 0
+        if rng.random() < 0.4:
+            k = int(rng.integers(1, 30)); ops.append((4, k)); q += k
+        span = sum(k for o, k in ops if o in (0, 2, 3, 7, 8))
+        pos = int(rng.integers(0, max(1, ref_len - span - 1)))
+        seq = "".join(rng.choice(list("ACGTN"), q, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        qual = rng.choice([37, 25, 11, 2], q, p=[0.8, 0.12, 0.06, 0.02]).astype(np.uint8)
+        segs.append(Segment(flag=int(rng.choice([0, 16, 99, 147])), reference_start=pos, cigar=ops,
+                            template_length=int(rng.integers(-500, 500)), query_sequence=seq, query_qualities=qual.tolist()))
+    return segs
+
+
+def test_unsorted_input_gives_the_same_table(runner, scheme):
+    """The kernels exploit coordinate order (LDS windows) but must not rely on it."""
+    g, pr, amps, mn, mx, mpl = scheme
+    segs = synth.make_mixed_segments(g, amps, 6000, seed=21)
+    rng = np.random.default_rng(21)
+    perm = rng.permutation(len(segs))
+    sorted_b = ReadBatch.from_segments(segs)
+    shuffled = ReadBatch.from_segments([segs[i] for i in perm])
+    a = oracle.process(shuffled, g.size, mn, mx, mpl, 20, 4)
+    d = runner.process(shuffled, g.size, mn, mx, mpl, 20, 4)
+    assert_same(a, d, shuffled)
+    assert np.array_equal(d.counts, runner.process(sorted_b, g.size, mn, mx, mpl, 20, 4).counts)
+
+
+def test_sparse_coverage_of_a_large_reference(runner):
+    """2 Mb reference at < 1 x: every tile moves the LDS window; most adds fall outside it."""
+    G = 2_000_000
+    rng = np.random.default_rng(22)
+    primers = sorted((int(s), int(s) + 25) for s in rng.integers(0, G - 30, 400))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, 0)
+    segs = synth.random_segments(rng, 8000, G, primers, domain_errors=False)
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, 20, 4)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    assert good.n > 7000
+    assert_same(oracle.process(good, G, mn, mx, mpl, 20, 4), runner.process(good, G, mn, mx, mpl, 20, 4), good)
+
+
+@pytest.mark.parametrize("max_len,max_ops,n", [(600, 16, 3000), (3000, 24, 1500), (9000, 120, 300)])
+def test_long_reads_with_many_ops(runner, max_len, max_ops, n):
+    """More CIGAR ops than the tile kernel's column (5), than the second pass's LDS columns (17), and reads
+    of thousands of bases: all take the deferred paths and must still be exact."""
+    G = 60_000
+    rng = np.random.default_rng(max_ops)
+    primers = sorted((int(s), int(s) + int(rng.integers(18, 31))) for s in rng.integers(0, G - 40, 120))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, 0)
+    segs = _long_read_segments(rng, n, G, max_len, max_ops)
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, 20, 4)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    assert len(ok) > 0.9 * n
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    a = oracle.process(good, G, mn, mx, mpl, 20, 4)
+    assert_same(a, runner.process(good, G, mn, mx, mpl, 20, 4), good)
+    assert int(np.diff(good.cig_off).max()) > min(max_ops - 4, 17)
+    # the statuses of the failing reads, too
+    d_all = runner.process(b, G, mn, mx, mpl, 20, 4)
+    assert np.array_equal(d_all.trim.status, a_all_status(b, G, mn, mx, mpl))
+
+
+def a_all_status(b, G, mn, mx, mpl):
+    return oracle.process(b, G, mn, mx, mpl, 20, 4).trim.status
+
+
+def test_one_very_long_read(runner):
+    """l_seq >= 65536 does not fit the tile kernel's 16-bit query offsets: exact serial path."""
+    from amplipy_amd.segment import Segment
+    G = 200_000
+    rng = np.random.default_rng(5)
+    L = 70_000
+    ops = [(4, 10), (0, 30_000), (2, 5), (0, 20_000), (1, 4), (0, L - 50_014), ]
+    seq = "".join(rng.choice(list("ACGT"), L)); qual = rng.choice([37, 25, 11], L, p=[0.9, 0.07, 0.03]).tolist()
+    s_long = Segment(flag=0, reference_start=1000, cigar=ops, template_length=0, query_sequence=seq, query_qualities=qual)
+    mn = np.full(G, -1, np.int32); mx = mn.copy(); mn[1000:1030] = 1000; mx[1000:1030] = 1030
+    short = _long_read_segments(rng, 200, G, 300, 6)
+    segs = sorted(short + [s_long], key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, 30, 20, 4)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    assert int(good.lseq.max()) == L
+    assert_same(oracle.process(good, G, mn, mx, 30, 20, 4), runner.process(good, G, mn, mx, 30, 20, 4), good)
