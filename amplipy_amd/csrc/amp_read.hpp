@@ -366,15 +366,106 @@ AMP_HD bool quality_window(TrimState &st, int32_t lseq, bool have_qual, const CB
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Closed forms of the trims for the commonest read: ONE match op covering the whole query
+// ("150M").  The loops above reduce to a few comparisons; the result is always [S a][op m][S c]
+// (zero-length parts absent; m == 0 collapses to [S L]).  Derived case by case from primer_clip /
+// quality_clip above and checked against them on the golden vectors (tests/hostsim runs both).
+// ---------------------------------------------------------------------------------------------
+struct SimpleCig {
+    uint32_t op;          // M, = or X
+    int32_t a, m, c;      // leading soft clip, match length, trailing soft clip; a + m + c == l_seq
+    template <class CB>
+    AMP_HD int store(const CB &b) const {
+        int n = 0;
+        if (a > 0) b.set(n++, ((uint32_t)a << 4) | OP_S);
+        if (m > 0) b.set(n++, ((uint32_t)m << 4) | op);
+        if (c > 0) b.set(n++, ((uint32_t)c << 4) | OP_S);
+        return n;
+    }
+};
+
+AMP_HD bool is_simple_cigar(int n, uint32_t w0, int32_t lseq) {
+    const uint32_t op = w0 & 15u;
+    return n == 1 && (op == OP_M || op == OP_EQ || op == OP_X) && lseq > 0 && (int32_t)(w0 >> 4) == lseq;
+}
+
+// trim_primers for a simple read; `sc` starts as {op, 0, l_seq, 0}
+AMP_HD void trim_primers_simple(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, SimpleCig &sc) {
+    const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
+    const int32_t rs = st.pos, L = lseq;
+    if ((uint32_t)rs >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }       // A:450
+    const int32_t re1 = rs + L - 1;
+    if ((uint32_t)re1 >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }      // A:451
+    const int32_t left_max_end = P.max_end[rs];
+    const int32_t right_min_start = P.min_start[re1];
+    const int32_t at = tlen < 0 ? -tlen : tlen;
+    const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;              // A:452
+    if (!(is_paired && isize_flag && is_reverse) && left_max_end >= 0) {                   // A:460
+        st.flags |= AMP_TRIM_PRIMER_START;
+        // pos_on_query([op L], left_max_end + 1): inside the op when ref_pos <= rs + L, else the query length
+        const int64_t rp = (int64_t)left_max_end + 1;
+        const int32_t del = rp <= (int64_t)rs + L ? (int32_t)(rp - rs) : L;
+        if (del != 0) {
+            if (del < 0) { sc.a = L; sc.m = 0; }                               // A:483-485: whole op -> S, start unchanged
+            else if (del >= L) { sc.a = L; sc.m = 0; st.pos += L; }
+            else { sc.a = del; sc.m = L - del; st.pos += del; }
+        }
+    }
+    if (!(is_paired && isize_flag && !is_reverse) && right_min_start >= 0) {               // A:517
+        st.flags |= AMP_TRIM_PRIMER_END;
+        if (sc.m > 0) {
+            const int64_t qp = (int64_t)right_min_start <= (int64_t)st.pos + sc.m ? (int64_t)sc.a + ((int64_t)right_min_start - st.pos) : (int64_t)L;
+            const int64_t del = (int64_t)L - qp;                               // >= 0; may exceed the match length
+            if (del > 0) {
+                if (del >= sc.m) { sc.a = L; sc.m = 0; }                       // everything soft-clipped
+                else { sc.c = (int32_t)del; sc.m -= (int32_t)del; }
+            }
+        }
+    }
+}
+
+// trim_quality_apply for a simple read (the window of quality_window is lo = a, qlen = m)
+AMP_HD void trim_quality_apply_simple(TrimState &st, bool is_reverse, int32_t i, int32_t qlen, SimpleCig &sc) {
+    if (sc.m <= 0) return;
+    if (is_reverse) {
+        const int32_t del = i;                     // pos_on_ref(del + qs - 1) > pos  <=>  del >= 2  (A:591-594)
+        if (del >= 2) {
+            st.flags |= AMP_TRIM_QUALITY;
+            sc.a += del; sc.m -= del;              // reference_start is NOT advanced
+            if (sc.m == 0) { sc.a += sc.c; sc.c = 0; }
+        }
+    } else {
+        const int32_t del = qlen - i;
+        if (del != 0) {                                                                    // A:656
+            st.flags |= AMP_TRIM_QUALITY;
+            sc.c += del; sc.m -= del;
+            if (sc.m == 0) { sc.a += sc.c; sc.c = 0; }
+        }
+    }
+}
+
 // Whole trim_read (A:426-687) for one read, scanning qualities serially.
 template <class CB>
 AMP_HD void trim_read_serial(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
                              const uint8_t *qual, bool have_qual, CB &cur, CB &tmp) {
+    const bool rev = (flag & 0x10u) != 0;
+    if (st.n == 1 && is_simple_cigar(1, cur.get(0), lseq)) {
+        SimpleCig sc{cur.get(0) & 15u, 0, lseq, 0};
+        trim_primers_simple(P, st, flag, tlen, lseq, sc);
+        if (st.err) return;
+        st.n = sc.store(cur);
+        if (!have_qual) { st.err = AMP_RS_NO_QUAL; return; }
+        const int32_t lo = sc.m > 0 ? sc.a : lseq, qlen = sc.m;
+        const int32_t i = quality_scan(qual + lo, qlen, P.window, P.min_quality, rev);
+        trim_quality_apply_simple(st, rev, i, qlen, sc);
+        st.n = sc.store(cur);
+        return;
+    }
     trim_primers(P, st, flag, tlen, lseq, cur, tmp);
     if (st.err) return;
     int32_t qs, lo, qlen;
     if (!quality_window(st, lseq, have_qual, cur, qs, lo, qlen)) return;
-    const bool rev = (flag & 0x10u) != 0;
     int32_t i = quality_scan(qual + lo, qlen, P.window, P.min_quality, rev);
     trim_quality_apply(st, rev, i, qlen, qs, cur, tmp);
 }

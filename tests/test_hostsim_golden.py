@@ -56,3 +56,52 @@ def test_device_read_logic_matches_oracle_random(seed, mq, w):
     assert np.array_equal(a.counts, d.counts)
     assert np.array_equal(np.sort(a.events, order=["ref_pos", "read", "q_from", "q_to"]),
                           np.sort(d.events, order=["ref_pos", "read", "q_from", "q_to"]))
+
+
+@pytest.mark.parametrize("seed,mq,w,off", [(11, 20, 4, 0), (12, 20, 4, 7), (13, 35, 3, 3), (14, 2, 8, 1), (15, 20, 40, 0)])
+def test_closed_form_trims_of_single_op_reads(seed, mq, w, off):
+    """Reads whose CIGAR is one match op take closed-form trims on the device (amp_read.hpp SimpleCig);
+    the oracle walks the general loops.  Dense random coverage of their cases: reads starting / ending inside,
+    before and after primers (offsets make `del` negative), whole-read clips, every strand / pairing flag,
+    insert sizes on both sides of the A:452 rule, low-quality runs at both ends, missing qualities."""
+    from amplipy_amd.segment import Segment
+    from tests import hostsim
+    G = 4000
+    rng = np.random.default_rng(seed)
+    starts = np.sort(rng.choice(np.arange(10, G - 60), 60, replace=False))
+    pr = [(int(s), int(s) + int(rng.integers(15, 31))) for s in starts]
+    mn, mx, mpl = oracle.find_overlapping_primers(G, pr, off)
+    segs = []
+    for _ in range(12000):
+        L = int(rng.integers(1, 90))
+        ps, pe = pr[int(rng.integers(0, len(pr)))]
+        mode = rng.random()
+        if mode < 0.45:
+            pos = ps + int(rng.integers(-12 - off, pe - ps + 12 + off))
+        elif mode < 0.9:
+            pos = pe + int(rng.integers(-12 - off, 12 + off)) - L
+        else:
+            pos = int(rng.integers(0, G))
+        pos = min(max(pos, 0), G - L)
+        q = rng.choice([37, 25, 11, 2], L, p=[0.7, 0.15, 0.1, 0.05])
+        if rng.random() < 0.3:
+            k = int(rng.integers(0, L + 1)); q[:k] = 2
+        if rng.random() < 0.3:
+            k = int(rng.integers(0, L + 1)); q[L - k:] = 2
+        quals = None if rng.random() < 0.02 else q.tolist()
+        tl = int(rng.choice([0, L, L + mpl, L + mpl + 1, 400, -400, -(L + mpl + 1), -L]))
+        segs.append(Segment(flag=int(rng.choice([0, 16, 1, 17, 99, 147, 83, 163])), reference_start=pos,
+                            cigar=[(int(rng.choice([0, 7, 8])), L)], template_length=tl,
+                            query_sequence="".join(rng.choice(list("ACGT"), L)), query_qualities=quals))
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, mq, w, do_count=False)
+    d = hostsim.process(b, G, mn, mx, mpl, mq, w, do_count=False)
+    assert np.array_equal(a.trim.status, d.trim.status)
+    ok = a.trim.status == 0
+    assert ok.mean() > 0.9 and (~ok).any()
+    assert np.array_equal(a.trim.new_pos[ok], d.trim.new_pos[ok])
+    assert np.array_equal(a.trim.ref_len, d.trim.ref_len)
+    assert np.array_equal(a.trim.trim_flags, d.trim.trim_flags)
+    assert np.array_equal(a.trim.new_ncig, d.trim.new_ncig)
+    assert np.array_equal(a.trim.compact_cigars(), d.trim.compact_cigars())
+    assert len(set(a.trim.trim_flags.tolist())) >= 4          # the cases are really visited

@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from amplipy_amd import lib, synth, synth_torch, abi
+g = synth.make_genome(); primers, amps = synth.make_artic_scheme(); G = int(g.size)
+n = synth.reads_for_depth(10000)
+mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
+for frac in (0.10, 0.0, 1.0):
+    b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0", indel_frac=frac); torch.cuda.synchronize()
+    e = lib.Engine(G); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True); e.reserve_events(1 << 22)
+    rd = b.struct()
+    ts = []
+    for it in range(6):
+        e.reset(); e.process_device(rd, 0, None); e.sync(); ts.append(e.last_kernel_ms())
+    print("indel_frac %.2f: k_tile %.4f ms, all kernels %.4f ms" % (frac, np.mean([t[1] for t in ts[2:]]), np.mean([t[0] for t in ts[2:]])))
+    e.close()
