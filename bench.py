@@ -39,6 +39,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is th
 
 
 def main():
+    # RCCL prints a banner on stdout when a communicator is created; the contract is ONE JSON line on
+    # stdout, so everything else written to fd 1 (from any library) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -47,6 +52,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=12, help="passes of the CPU baseline over the batch (0 = skip)")
     ap.add_argument("--variant", type=int, default=2)
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -57,9 +63,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
 
@@ -247,7 +254,7 @@ def main():
             "cpu_baseline": cpu,
             "gen_seconds": round(t_gen, 2),
         }
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     for sl in slots:
         sl.eng.close()
     if dist is not None:
