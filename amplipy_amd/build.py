@@ -40,7 +40,7 @@ BAM_OUT = os.path.join(_HERE, "libampbam.so")
 def build_bam(force=False, verbose=False):
     if not force and os.path.isfile(BAM_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(BAM_OUT) for d in BAM_DEPS):
         return BAM_OUT
-    cmd = [shutil.which("g++") or "g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", BAM_OUT, BAM_SRC, "-lz", "-pthread"]
+    cmd = [shutil.which("g++") or "g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", BAM_OUT, BAM_SRC, "-lz", "-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

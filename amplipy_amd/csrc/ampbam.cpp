@@ -5,6 +5,7 @@
 // the writer can copy the unchanged parts of a record straight from the input image.
 #include "../../include/ampbam.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -52,6 +53,61 @@ inline uint16_t reg2bin(int64_t beg, int64_t end) {
     return 0;
 }
 
+// DEFLATE through libdeflate when the shared object is present (2-3x zlib on 64 KiB blocks; htslib
+// makes the same choice), resolved at run time so that there is no build-time dependency; zlib otherwise.
+// AMPBAM_ZLIB=1 in the environment forces zlib.
+struct LibDeflate {
+    void *(*alloc_d)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_d)(void *) = nullptr;
+    void *(*alloc_c)(int) = nullptr;
+    size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*free_c)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        const char *force = std::getenv("AMPBAM_ZLIB");
+        if (force && force[0] && force[0] != '0') return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc_d = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        free_d = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        free_c = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc_d && decompress && free_d && alloc_c && compress && free_c && crc;
+    }
+};
+const LibDeflate &libdeflate() { static const LibDeflate L; return L; }
+
+// one worker's inflater
+struct Inflater {
+    void *ld = nullptr;
+    z_stream zs;
+    bool z_ok = false;
+    Inflater() {
+        if (libdeflate().ok) ld = libdeflate().alloc_d();
+        if (!ld) { std::memset(&zs, 0, sizeof(zs)); z_ok = inflateInit2(&zs, -15) == Z_OK; }
+    }
+    ~Inflater() { if (ld) libdeflate().free_d(ld); else if (z_ok) inflateEnd(&zs); }
+    bool run(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, uint32_t want_crc) {
+        if (ld) {
+            size_t got = 0;
+            if (libdeflate().decompress(ld, in, in_len, out, out_len, &got) != 0 || got != out_len) return false;
+            return libdeflate().crc(0, out, out_len) == want_crc;
+        }
+        if (!z_ok) return false;
+        inflateReset(&zs);
+        zs.next_in = const_cast<Bytef *>(in); zs.avail_in = (uInt)in_len;
+        zs.next_out = out; zs.avail_out = (uInt)out_len;
+        if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) return false;
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)out_len) == want_crc;
+    }
+};
+
 const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
@@ -86,6 +142,7 @@ struct ampbam_file {
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
     std::vector<uint64_t> rec_off;          // offset of every record's block_size field (+ end sentinel)
+    std::vector<uint64_t> rec_info;         // l_seq | n_cigar_op << 32 | flag << 48, so that planning a batch does not touch the image
     int n_threads = 1;
     std::string err;
     // decode outputs (reused)
@@ -100,7 +157,8 @@ struct ampbam_file {
 struct ampbam_writer {
     FILE *fp = nullptr;
     int level = -1, n_threads = 1;
-    std::vector<uint8_t> pend;              // uncompressed bytes not yet written
+    Bytes pend;                             // uncompressed bytes not yet written (no zero fill on growth)
+    Bytes comp;                             // compressed blocks of one flush, at a fixed stride
     std::string err;
 };
 
@@ -170,53 +228,83 @@ int ampbam_open(const char *path, int n_threads, ampbam_file **out) {
     if (!f->data.resize(total + 16)) return fail(AMPBAM_ENOMEM, "alloc");
     std::memset(f->data.data() + total, 0, 16);
 
-    // ---- inflate, in parallel ---------------------------------------------------------------
+    // ---- inflate on worker threads; this thread parses the header and indexes the records behind them --
+    const int64_t nb = (int64_t)blocks.size(), grain = 8, n_chunks = (nb + grain - 1) / grain;
+    std::vector<std::atomic<uint8_t>> done((size_t)n_chunks);
+    for (auto &x : done) x.store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> next_chunk{0};
     std::atomic<int> bad{0};
-    const int64_t nb = (int64_t)blocks.size(), grain = 16;
-    parallel_for(f->n_threads, (nb + grain - 1) / grain, [&](int64_t c) {
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
-        for (int64_t k = c * grain; k < std::min(nb, (c + 1) * grain); ++k) {
-            const Block &b = blocks[(size_t)k];
-            if (b.out_len == 0) continue;
-            inflateReset(&zs);
-            zs.next_in = const_cast<Bytef *>(raw.data() + b.in_off); zs.avail_in = (uInt)b.in_len;
-            zs.next_out = f->data.data() + b.out_off; zs.avail_out = (uInt)b.out_len;
-            const int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), f->data.data() + b.out_off, (uInt)b.out_len) != b.crc) { bad = 1; break; }
+    auto worker = [&]() {
+        Inflater inf;
+        for (;;) {
+            const int64_t c = next_chunk.fetch_add(1);
+            if (c >= n_chunks) break;
+            for (int64_t k = c * grain; k < std::min(nb, (c + 1) * grain) && !bad.load(std::memory_order_relaxed); ++k) {
+                const Block &b = blocks[(size_t)k];
+                if (b.out_len && !inf.run(raw.data() + b.in_off, b.in_len, f->data.data() + b.out_off, b.out_len, b.crc)) bad = 1;
+            }
+            done[(size_t)c].store(1, std::memory_order_release);
         }
-        inflateEnd(&zs);
-    });
-    if (bad) return fail(AMPBAM_EFORMAT, "inflate / CRC");
-    raw.clear(); raw.shrink_to_fit();
+    };
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<int64_t>(f->n_threads, std::max<int64_t>(n_chunks, 1));
+    for (int t = 0; t < nt; ++t) th.emplace_back(worker);
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{th};
+
+    size_t avail = 0;          // bytes of the image known to be inflated
+    int64_t seen = 0;          // chunks consumed into `avail`
+    auto need = [&](size_t upto) -> bool {     // wait until image bytes [0, upto) exist
+        if (upto > total) return false;
+        while (avail < upto) {
+            if (seen >= n_chunks) return false;
+            if (done[(size_t)seen].load(std::memory_order_acquire)) {
+                const int64_t last = std::min(nb, (seen + 1) * grain) - 1;
+                avail = blocks[(size_t)last].out_off + blocks[(size_t)last].out_len;
+                ++seen;
+            } else {
+                if (bad.load(std::memory_order_relaxed)) return false;
+                std::this_thread::yield();
+            }
+        }
+        return true;
+    };
+    auto fail2 = [&](const char *msg) { bad = 1; for (auto &x : th) if (x.joinable()) x.join(); return fail(AMPBAM_EFORMAT, msg); };
 
     // ---- BAM header ----------------------------------------------------------------------------
     const uint8_t *d = f->data.data();
     size_t o = 0;
-    if (total < 12 || std::memcmp(d, "BAM\1", 4) != 0) return fail(AMPBAM_EFORMAT, "BAM magic");
+    if (!need(12) || std::memcmp(d, "BAM\1", 4) != 0) return fail2("BAM magic");
     const size_t l_text = le32(d + 4);
-    if (total < 12 + l_text) return fail(AMPBAM_EFORMAT, "header text");
+    if (!need(12 + l_text)) return fail2("header text");
     f->text_off = 8; f->text_len = l_text;
     o = 8 + l_text;
     const int32_t n_ref = (int32_t)le32(d + o); o += 4;
-    if (n_ref < 0) return fail(AMPBAM_EFORMAT, "n_ref");
+    if (n_ref < 0) return fail2("n_ref");
     for (int32_t r = 0; r < n_ref; ++r) {
-        if (total < o + 4) return fail(AMPBAM_EFORMAT, "reference");
+        if (!need(o + 4)) return fail2("reference");
         const size_t l_name = le32(d + o); o += 4;
-        if (l_name == 0 || total < o + l_name + 4) return fail(AMPBAM_EFORMAT, "reference");
+        if (l_name == 0 || !need(o + l_name + 4)) return fail2("reference");
         f->ref_names.emplace_back((const char *)(d + o), l_name - 1); o += l_name;
         f->ref_lens.push_back((int32_t)le32(d + o)); o += 4;
     }
-    // ---- record index ------------------------------------------------------------------------
-    while (o < total) {
-        if (total - o < 4) return fail(AMPBAM_EFORMAT, "record size");
-        const size_t bs = le32(d + o);
-        if (bs < 32 || total - o - 4 < bs) return fail(AMPBAM_EFORMAT, "record");
-        f->rec_off.push_back(o);
-        o += 4 + bs;
-    }
+    // ---- record index (+ the fixed fields batch planning needs) ---------------------------------
+    try {
+        f->rec_off.reserve(total / 200 + 16); f->rec_info.reserve(total / 200 + 16);
+        while (o < total) {
+            if (!need(o + 36)) return fail2("record");
+            const size_t bs = le32(d + o);
+            if (bs < 32 || total - o - 4 < bs) return fail2("record");
+            const uint8_t *c = d + o + 4;
+            const uint64_t n_cig = le16(c + 12), flag = le16(c + 14), l_seq = le32(c + 16), l_name = c[8];
+            if (32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) return fail2("record fields");
+            f->rec_off.push_back(o);
+            f->rec_info.push_back(l_seq | (n_cig << 32) | (flag << 48));
+            o += 4 + bs;
+        }
+    } catch (const std::bad_alloc &) { bad = 1; for (auto &x : th) if (x.joinable()) x.join(); return fail(AMPBAM_ENOMEM, "alloc"); }
+    for (auto &x : th) if (x.joinable()) x.join();
+    if (bad) return fail(AMPBAM_EFORMAT, "inflate / CRC");
+    raw.clear(); raw.shrink_to_fit();
     f->rec_off.push_back(o);
     *out = f;
     return AMPBAM_OK;
@@ -251,10 +339,8 @@ int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *ou
         f->src_index.reserve((size_t)count); f->cig_off.reserve((size_t)count + 1); f->seq_off.reserve((size_t)count + 1);
         uint64_t co = 0, so = 0;
         for (int64_t r = first; r < first + count; ++r) {
-            const uint8_t *c = d + f->rec_off[(size_t)r] + 4;
-            const uint32_t n_cig = le16(c + 12), flag = le16(c + 14), l_seq = le32(c + 16), l_name = c[8];
-            const uint64_t bs = f->rec_off[(size_t)r + 1] - f->rec_off[(size_t)r] - 4;
-            if (32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) { f->err = "record " + std::to_string(r) + " is shorter than its fields"; return AMPBAM_EFORMAT; }
+            const uint64_t info = f->rec_info[(size_t)r];
+            const uint32_t l_seq = (uint32_t)info, n_cig = (uint32_t)(info >> 32) & 0xFFFFu, flag = (uint32_t)(info >> 48);
             if ((flag & 4u) || n_cig == 0) continue;                                    // AmpliPy.py:902
             f->src_index.push_back(r);
             co += n_cig; so += ((uint64_t)l_seq + 7) & ~7ull;
@@ -302,37 +388,64 @@ int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *ou
 // ---------------------------------------------------------------------------------------------
 // writer
 // ---------------------------------------------------------------------------------------------
+static bool append(Bytes &b, const void *src, size_t n) {
+    const size_t at = b.size();
+    if (at + n > b.cap) {
+        size_t want = std::max(at + n, b.cap + b.cap / 2 + 4096);
+        uint8_t *q = (uint8_t *)std::realloc(b.p, want);
+        if (!q) return false;
+        b.p = q; b.cap = want;
+    }
+    std::memcpy(b.p + at, src, n);
+    b.n = at + n;
+    return true;
+}
+
 static int flush_blocks(ampbam_writer *w, bool all) {
-    const size_t BS = 0xFF00;
+    const size_t BS = 0xFF00, STRIDE = 65536 + 64;     // a BGZF block is at most 64 KiB
     const size_t nfull = w->pend.size() / BS, nblk = nfull + ((all && w->pend.size() % BS) ? 1 : 0);
     if (nblk == 0) return AMPBAM_OK;
-    std::vector<std::vector<uint8_t>> outb(nblk);
+    if (!w->comp.resize(nblk * STRIDE)) return AMPBAM_ENOMEM;
+    std::vector<uint32_t> out_len(nblk, 0);
     std::atomic<int> bad{0};
-    parallel_for(w->n_threads, (int64_t)nblk, [&](int64_t k) {
-        const size_t off = (size_t)k * BS, len = std::min(BS, w->pend.size() - off);
-        std::vector<uint8_t> &o = outb[(size_t)k];
-        o.resize(18 + compressBound((uLong)len) + 8);
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
-        zs.next_in = w->pend.data() + off; zs.avail_in = (uInt)len;
-        zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 18 - 8);
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END || clen + 26 > 65536) { bad = 1; return; }
-        const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        std::memcpy(o.data(), hdr, 16);
-        put16(o.data() + 16, (uint16_t)(clen + 25));
-        put32(o.data() + 18 + clen, (uint32_t)crc32(crc32(0L, Z_NULL, 0), w->pend.data() + off, (uInt)len));
-        put32(o.data() + 18 + clen + 4, (uint32_t)len);
-        o.resize(18 + clen + 8);
+    const int64_t grain = 4;
+    parallel_for(w->n_threads, ((int64_t)nblk + grain - 1) / grain, [&](int64_t ch) {
+        void *lc = libdeflate().ok ? libdeflate().alloc_c(w->level < 0 ? 6 : (w->level == 0 ? 1 : w->level)) : nullptr;
+        for (int64_t k = ch * grain; k < std::min<int64_t>((int64_t)nblk, (ch + 1) * grain); ++k) {
+            const size_t off = (size_t)k * BS, len = std::min(BS, w->pend.size() - off);
+            uint8_t *o = w->comp.data() + (size_t)k * STRIDE;
+            const size_t room = STRIDE - 18 - 8;
+            size_t clen = 0;
+            if (lc) {
+                clen = libdeflate().compress(lc, w->pend.data() + off, len, o + 18, room);
+            } else {
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; break; }
+                zs.next_in = w->pend.data() + off; zs.avail_in = (uInt)len;
+                zs.next_out = o + 18; zs.avail_out = (uInt)room;
+                const int rc = deflate(&zs, Z_FINISH);
+                clen = rc == Z_STREAM_END ? zs.total_out : 0;
+                deflateEnd(&zs);
+            }
+            if (clen == 0 || clen + 26 > 65536) { bad = 1; break; }
+            const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            std::memcpy(o, hdr, 16);
+            put16(o + 16, (uint16_t)(clen + 25));
+            const uint32_t crc = libdeflate().ok ? libdeflate().crc(0, w->pend.data() + off, len)
+                                                 : (uint32_t)crc32(crc32(0L, Z_NULL, 0), w->pend.data() + off, (uInt)len);
+            put32(o + 18 + clen, crc);
+            put32(o + 18 + clen + 4, (uint32_t)len);
+            out_len[(size_t)k] = (uint32_t)(18 + clen + 8);
+        }
+        if (lc) libdeflate().free_c(lc);
     });
     if (bad) return AMPBAM_EIO;
-    for (auto &o : outb)
-        if (std::fwrite(o.data(), 1, o.size(), w->fp) != o.size()) return AMPBAM_EIO;
-    const size_t used = std::min(w->pend.size(), nblk * BS);
-    w->pend.erase(w->pend.begin(), w->pend.begin() + (ptrdiff_t)used);
+    for (size_t k = 0; k < nblk; ++k)
+        if (std::fwrite(w->comp.data() + k * STRIDE, 1, out_len[k], w->fp) != out_len[k]) return AMPBAM_EIO;
+    const size_t used = std::min(w->pend.size(), nblk * BS), rest = w->pend.size() - used;
+    if (rest) std::memmove(w->pend.data(), w->pend.data() + used, rest);       // < one block
+    w->pend.n = rest;
     return AMPBAM_OK;
 }
 
@@ -345,18 +458,19 @@ int ampbam_writer_open(const char *path, const char *header_text, int64_t header
     w->level = level; w->n_threads = pick_threads(n_threads);
     w->fp = std::fopen(path, "wb");
     if (!w->fp) { delete w; return AMPBAM_EIO; }
-    std::vector<uint8_t> &b = w->pend;
-    b.insert(b.end(), {'B', 'A', 'M', 1});
+    Bytes &b = w->pend;
     uint8_t t[4];
-    put32(t, (uint32_t)header_len); b.insert(b.end(), t, t + 4);
-    b.insert(b.end(), (const uint8_t *)header_text, (const uint8_t *)header_text + header_len);
-    put32(t, (uint32_t)like->ref_names.size()); b.insert(b.end(), t, t + 4);
-    for (size_t r = 0; r < like->ref_names.size(); ++r) {
+    bool okm = append(b, "BAM\1", 4);
+    put32(t, (uint32_t)header_len); okm = okm && append(b, t, 4);
+    okm = okm && append(b, header_text, (size_t)header_len);
+    put32(t, (uint32_t)like->ref_names.size()); okm = okm && append(b, t, 4);
+    for (size_t r = 0; okm && r < like->ref_names.size(); ++r) {
         const std::string &nm = like->ref_names[r];
-        put32(t, (uint32_t)nm.size() + 1); b.insert(b.end(), t, t + 4);
-        b.insert(b.end(), nm.begin(), nm.end()); b.push_back(0);
-        put32(t, (uint32_t)like->ref_lens[r]); b.insert(b.end(), t, t + 4);
+        put32(t, (uint32_t)nm.size() + 1); okm = okm && append(b, t, 4);
+        okm = okm && append(b, nm.c_str(), nm.size() + 1);
+        put32(t, (uint32_t)like->ref_lens[r]); okm = okm && append(b, t, 4);
     }
+    if (!okm) { std::fclose(w->fp); delete w; return AMPBAM_ENOMEM; }
     *out = w;
     return AMPBAM_OK;
 }
@@ -374,14 +488,13 @@ int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, 
         if (keep[i]) {
             const int64_t r = src_index[i];
             if (r < 0 || r >= n_rec || new_ncig[i] > 65535u) return AMPBAM_EINVAL;
-            const uint8_t *c = d + src->rec_off[(size_t)r] + 4;
             const uint64_t bs = src->rec_off[(size_t)r + 1] - src->rec_off[(size_t)r] - 4;
-            sz = 4 + bs - 4ull * le16(c + 12) + 4ull * new_ncig[i];
+            sz = 4 + bs - 4ull * ((src->rec_info[(size_t)r] >> 32) & 0xFFFFu) + 4ull * new_ncig[i];   // no touch of the image here
         }
         off[(size_t)i + 1] = off[(size_t)i] + sz;
     }
     const size_t base = w->pend.size();
-    try { w->pend.resize(base + (size_t)off[(size_t)n_rows]); } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
+    if (!w->pend.resize(base + (size_t)off[(size_t)n_rows])) return AMPBAM_ENOMEM;
     uint8_t *ob = w->pend.data() + base;
     const int64_t grain = 4096;
     parallel_for(w->n_threads, (n_rows + grain - 1) / grain, [&](int64_t ch) {
