@@ -19,7 +19,7 @@ import numpy as np
 
 from . import AMPLIPY_VERSION, abi, bamio, calling, lib
 from .batch import ReadBatch
-from .insertions import event_strings
+from .insertions import EventStore
 
 VERSION = AMPLIPY_VERSION
 PROGRESS_NUM_READS = 50000          # AmpliPy.py:19
@@ -229,7 +229,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                    sliding_window_width if sliding_window_width is not None else 4, run_trim, do_count)
 
     print_log("Processing reads...")
-    ins_pairs = []                       # (ref_pos, string) of every insertion event (host copy of each batch is at hand)
+    ins_store = EventStore()             # insertion events with their allele text (each batch's bases are at hand only now)
     pending = []
     s_i = None
     read_base = 0
@@ -251,7 +251,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         if do_count:
             ev = eng.events()
             new = ev[ev["read"] >= read_base] if read_base else ev
-            ins_pairs.extend(event_strings(batch, new, read_base))
+            ins_store.add(batch, new, read_base)
         read_base += batch.n
         del pending[:]
 
@@ -279,7 +279,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             if do_count:
                 ev = eng.events()
                 new = ev[ev["read"] >= read_base] if read_base else ev
-                ins_pairs.extend(event_strings(batch, new, read_base))
+                ins_store.add(batch, new, read_base)
             read_base += batch.n
         if nwriter is not None:
             nwriter.close()
@@ -305,7 +305,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                                  min_freq_variants if min_freq_variants is not None else 0,
                                  run_consensus, run_variants)
         eng.set_reference(ref_seq)
-        res = calling.call(eng, ref_seq, cp, lambda positions: calling.tallies_from_events(ins_pairs, positions))
+        res = calling.call(eng, ref_seq, cp, lambda positions: calling.tallies_from_events(ins_store.pairs(positions), positions))
         if run_variants:
             for r in res.records:
                 vcf.write(r)

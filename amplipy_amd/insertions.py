@@ -34,6 +34,43 @@ def event_strings(batch, events, read_base=0):
     return out
 
 
+class EventStore:
+    """Insertion events of many batches with their allele text, kept columnar: positions, one byte
+    blob and offsets.  Adding a batch is vectorised (no per-event Python); strings are only built for
+    the positions calling asks about (AmpliPy.py:745-748 keys, restricted to where they can matter)."""
+
+    def __init__(self):
+        self._pos = []; self._len = []; self._blob = []
+
+    def add(self, batch, events, read_base=0):
+        if events.size == 0:
+            return
+        i = events["read"].astype(np.int64) - int(read_base)
+        start = batch.seq_off[i].astype(np.int64) + events["q_from"].astype(np.int64)
+        length = np.maximum(events["q_to"].astype(np.int64) - events["q_from"].astype(np.int64), 0)
+        total = int(length.sum())
+        first = np.cumsum(length) - length                       # offset of each event in the blob
+        b = np.repeat(start - first, length) + np.arange(total, dtype=np.int64)     # base index of every blob byte
+        nib = (batch.seq[b >> 1] >> ((1 - (b & 1)) * 4).astype(np.uint8)) & 15
+        self._pos.append(events["ref_pos"].astype(np.int64)); self._len.append(length); self._blob.append(_NT16[nib])
+
+    def __len__(self):
+        return int(sum(p.size for p in self._pos))
+
+    def pairs(self, positions=None):
+        """[(ref_pos, string)] of the events at ``positions`` (all events when None), in insertion order."""
+        out = []
+        want = None if positions is None else np.fromiter(positions, np.int64, len(positions))
+        for pos, length, blob in zip(self._pos, self._len, self._blob):
+            off = np.cumsum(length) - length
+            sel = np.arange(pos.size) if want is None else np.nonzero(np.isin(pos, want))[0]
+            raw = blob.tobytes()
+            for k in sel.tolist():
+                o = int(off[k])
+                out.append((int(pos[k]), raw[o:o + int(length[k])].decode("ascii")))
+        return out
+
+
 def tally(pairs):
     """Counter {(ref_pos, string): count}."""
     return Counter(pairs)

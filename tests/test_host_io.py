@@ -87,3 +87,23 @@ def test_argument_validation_exits_like_the_reference(capsys):
     with pytest.raises(SystemExit):
         amplipy.run_amplipy()
     assert "Not running any of the AmpliPy operations" in capsys.readouterr().err
+
+
+def test_event_store_matches_per_event_strings():
+    """EventStore (vectorised, what run_amplipy keeps) against insertions.event_strings (per event)."""
+    from amplipy_amd import insertions
+    from oracle import oracle
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    segs = synth.make_mixed_segments(g, amps, 3000, seed=8)
+    b = ReadBatch.from_segments(segs)
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, [(s, e) for s, e, _ in primers], 0)
+    r = oracle.process(b, g.size, mn, mx, mpl, 20, 4, read_base=1000)
+    assert r.events.size > 500
+    st = insertions.EventStore()
+    half = r.events.size // 2
+    st.add(b, r.events[:half], 1000); st.add(b, r.events[half:], 1000); st.add(b, r.events[:0], 0)
+    want = insertions.event_strings(b, r.events, 1000)
+    assert st.pairs() == want and len(st) == len(want)
+    some = set(p for p, _ in want[::7])
+    assert st.pairs(some) == [x for x in want if x[0] in some]
+    assert st.pairs(set()) == []
