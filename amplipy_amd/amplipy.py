@@ -23,7 +23,8 @@ from .insertions import EventStore
 
 VERSION = AMPLIPY_VERSION
 PROGRESS_NUM_READS = 50000          # AmpliPy.py:19
-BATCH_READS = 1 << 18
+BATCH_READS = 1 << 18              # reads per device batch on the Python-codec path (one Rec object each)
+NATIVE_BATCH_READS = 1 << 20       # records per device batch on the libampbam path (about 0.3 GB of host arrays at 150 bp)
 
 DEFAULTS = dict(min_depth_consensus=10, min_depth_variants=1, min_freq_consensus=0, min_freq_variants=0.03,
                 min_length=30, min_quality=20, primer_pos_offset=0, sliding_window_width=4, unknown_symbol="N")
@@ -120,7 +121,8 @@ def open_native_bam(input_fn, output_fn):
     writer = None
     if output_fn is not None:
         hdr = bamio.Header(src.header_text, src.references).with_amplipy_pg(VERSION, " ".join(sys.argv))
-        writer = bam_native.BamWriter(output_fn, hdr.text, src)
+        # zlib's default level like htslib; AMPLIPY_BAM_LEVEL=1 trades file size for speed
+        writer = bam_native.BamWriter(output_fn, hdr.text, src, level=int(os.environ.get("AMPLIPY_BAM_LEVEL", "-1")))
     return src, writer
 
 
@@ -259,8 +261,8 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
         # re-encodes the kept ones; no per-read Python object exists on this path
         src, nwriter = native
-        for first in range(0, src.n_records, BATCH_READS):
-            count = min(BATCH_READS, src.n_records - first)
+        for first in range(0, src.n_records, NATIVE_BATCH_READS):
+            count = min(NATIVE_BATCH_READS, src.n_records - first)
             batch, _ = src.decode(first, count)
             for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
                 if s_i:

@@ -31,6 +31,11 @@ for it, cmd in enumerate(("aio", "aio", "variants")):
     else:
         argv = ["variants", "-i", os.path.join(tmp, "t0.bam"), "-r", os.path.join(tmp, "ref.fas"), "-o", outs["v"]]
     t0 = time.perf_counter()
-    amplipy.main(argv)
+    if it == 1 and os.environ.get("PROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable(); amplipy.main(argv); pr.disable()
+        pstats.Stats(pr, stream=sys.stdout).sort_stats("cumulative").print_stats(22)
+    else:
+        amplipy.main(argv)
     dt = time.perf_counter() - t0
     print("%s: %.3fs -> %.2f M reads/s (whole command)" % (cmd, dt, b.n / dt / 1e6))
