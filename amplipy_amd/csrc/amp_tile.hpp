@@ -1,9 +1,9 @@
 // amp_tile.hpp -- the fused trim + pileup kernel (variant 2), written for CDNA4 / gfx950.
 //
 // Work decomposition (nothing like the reference's per-read Python loop, A:896-915):
-//   * a wave owns a TILE of 64 consecutive reads; a block of T_WAVES waves (one block per CU)
-//     walks a contiguous range of tiles of the coordinate-sorted batch, so it touches a bounded
-//     reference window
+//   * a wave owns a TILE of 64 consecutive reads; a block of T_WAVES waves (two blocks per CU, the
+//     grid about eight times oversubscribed) walks a contiguous range of tiles of the
+//     coordinate-sorted batch, so it touches a bounded reference window
 //   * per-position counters are PRIVATISED in LDS: win[6][W] uint32 for reference positions
 //     [win_base, win_base+W); lanes add with LDS atomics (ds_add_u32) and the block flushes
 //     the non-zero counters with global atomics when the window has to move / at the end.
@@ -12,7 +12,7 @@
 //   * the tile alternates between two lane mappings:
 //       lane = read   P1  primer clips on the CIGAR held in LDS (one column per lane)
 //                     P3  quality clip (partial windows + CIGAR rewrite), outputs, match-op
-//                         SEGMENTS, deletions / insertion events
+//                         SEGMENTS
 //       lane = chunk  P2  sliding-window quality scan: a chunk is 8 consecutive window START
 //                         positions; eight W-byte sums (v_sad_u8) from a 16-byte neighbourhood,
 //                         first / last failing full window per read by one LDS atomicMin
@@ -23,11 +23,13 @@
 //                         different banks.
 //     Chunk lanes find their owner through a byte map in LDS that the read lanes fill
 //     (chunk -> read for P2, chunk -> segment for P4); the map aliases the spare CIGAR buffer.
-//   * anything unusual is DEFERRED to the lane-per-read kernel (k_reads_deferred in
-//     amplihip.hip), which runs the exact serial code of amp_read.hpp: reads with more CIGAR
-//     ops than the LDS columns hold, reads of 64 k bases or more, reads whose trimmed CIGAR is
-//     not regular (clips only at the ends, body of M/=/X/I/D/N), reads whose segments do not
-//     fit the tile's segment table, and (status only) reads on which a chunk lane met an error.
+//   * everything else is DEFERRED through the block's own segment of a list to the second pass in
+//     amplihip.hip: "light" entries (deletions and insertion events of reads whose match bases were
+//     counted here) to k_deferred_light, "heavy" entries to k_deferred_heavy, which runs the exact code
+//     of amp_read.hpp -- reads with more CIGAR ops than the LDS columns hold, reads of 64 k bases or
+//     more, reads whose trimmed CIGAR is not regular (clips only at the ends, body of M/=/X/I/D/N),
+//     reads whose segments do not fit the tile's segment table, and (status only) reads on which a
+//     chunk lane met an error.
 #pragma once
 
 #include "amp_read.hpp"
