@@ -78,10 +78,13 @@ struct LdsCig {
     __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * TILE] = v; }
 };
 
+// Lanes of one wave hand data to each other through LDS only: the fences are restricted to the local
+// address space, so the wait is `s_waitcnt lgkmcnt(0)` and global loads / stores in flight (prefetched
+// qualities, the outputs of P3) are not drained at every phase change.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 __device__ __forceinline__ void lds_add(lds_u32 *p, uint32_t v) {
@@ -458,10 +461,20 @@ __device__ __forceinline__ void p4_round(const ChunkEnv &E, int lane, uint32_t l
 }
 
 // ---------------------------------------------------------------------------------------
-template <bool STAMPS>
+// Per-read hand-over between the kernels of the split pipeline (variant 3): what P1 knows about a read
+// after the primer clips.  The primer-trimmed CIGAR itself travels through the read's output slot.
+struct SplitDesc {
+    int32_t *pos;      // reference_start after the start clip
+    uint32_t *lohi;    // aligned-quality window lo | hi << 16
+    uint32_t *meta;    // n ops | trim flags << 8 | status << 16 | SD_* bits
+    uint32_t *ff;      // result of the window scan (S_FF encoding), 0xFFFF = no full window failed
+};
+constexpr uint32_t SD_DEFER = 1u << 24, SD_HAVE_QUAL = 1u << 25, SD_CAN_Q = 1u << 26, SD_REV = 1u << 27;
+
+template <bool STAMPS, bool SPLIT>
 __global__ void __launch_bounds__(T_WAVES * 64, 4)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
-       uint32_t *dcnt, int tiles_per_block, uint32_t phases) {
+       uint32_t *dcnt, int tiles_per_block, uint32_t phases, SplitDesc sd) {
     __shared__ BlockLds L;
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -526,24 +539,32 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const int64_t i = tile * TILE + lane;
         const bool valid = i < n;
         int32_t lseq = 0, pos = 0, tlen = 0;
-        uint32_t flag = 0, c0 = 0, off8 = 0;
+        uint32_t flag = 0, c0 = 0, off8 = 0, meta = 0, lohi = 0;
         int ncig = 0;
         if (valid) {
-            pos = rd.pos[i]; flag = rd.flag[i]; tlen = rd.tlen[i]; lseq = (int32_t)rd.lseq[i];
-            c0 = rd.cig_off32[i]; ncig = (int)(rd.cig_off32[i + 1] - c0); off8 = rd.seq_off8[i];
+            lseq = (int32_t)rd.lseq[i]; c0 = rd.cig_off32[i]; off8 = rd.seq_off8[i];
+            if (SPLIT) { meta = sd.meta[i]; lohi = sd.lohi[i]; pos = sd.pos[i]; }
+            else { pos = rd.pos[i]; flag = rd.flag[i]; tlen = rd.tlen[i]; ncig = (int)(rd.cig_off32[i + 1] - c0); }
         }
         const size_t slot = (size_t)c0 + 3 * (size_t)(valid ? i : 0);
         const int64_t boff = (int64_t)off8 * 8;
         const uint8_t *qual = rd.qual + boff;
-        bool defer_full = valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
+        bool defer_full = SPLIT ? (meta & SD_DEFER) != 0 : valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
         const bool mine = valid && !defer_full;
-        const bool have_qual = mine && lseq > 0 && qual[0] != 0xFF;
-        const bool rev = (flag & 0x10u) != 0;
+        const bool have_qual = SPLIT ? (meta & SD_HAVE_QUAL) != 0 : mine && lseq > 0 && qual[0] != 0xFF;
+        const bool rev = SPLIT ? (meta & SD_REV) != 0 : (flag & 0x10u) != 0;
         TrimState ts{pos, ncig, 0u, 0};
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
         bool can_q = false;
-        if (mine) {
+        if (SPLIT) {
+            // k_trim did the primer clips: its CIGAR is in the read's output slot
+            ts.n = (int)(meta & 0xFFu); ts.flags = (meta >> 8) & 0xFFu; ts.err = (int)((meta >> 16) & 0xFFu);
+            can_q = (meta & SD_CAN_Q) != 0;
+            qs = lo = (int32_t)(lohi & 0xFFFFu); qlen = (int32_t)(lohi >> 16) - lo;
+            if (mine && !ts.err)
+                for (int k = 0; k < ts.n; ++k) cur.set(k, out.new_cig[slot + k]);
+        } else if (mine) {
             for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
             if (P.do_trim) {
                 trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
@@ -568,12 +589,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const bool par_scan = mine && can_q && Wd <= 8 && (phases & 2u);
         const int32_t hi = lo + qlen;
         uint32_t nch2 = 0;
-        if (par_scan && qlen >= Wd) nch2 = (uint32_t)(((hi - Wd) >> 3) - (lo >> 3) + 1);
+        if (!SPLIT && par_scan && qlen >= Wd) nch2 = (uint32_t)(((hi - Wd) >> 3) - (lo >> 3) + 1);
         uint32_t total2;
         const uint32_t cb2 = wave_excl_scan(nch2, lane, total2);
         st[S_OFF8 * TILE + lane] = off8;
         st[S_LOHI * TILE + lane] = (uint32_t)lo | ((uint32_t)hi << 16);
-        st[S_FF * TILE + lane] = 0xFFFFu;
+        st[S_FF * TILE + lane] = (SPLIT && par_scan) ? sd.ff[i] : 0xFFFFu;
         st[S_REV * TILE + lane] = rev ? 1u : 0u;
         st[S_ERR * TILE + lane] = 0u;
         st[S_CB2 * TILE + lane] = cb2;
@@ -581,6 +602,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         AMP_STAMP(0);
         bs_c2 += total2;
         // =================================== P2: lane = chunk ===================================
+        if (!SPLIT)
         for (uint32_t base = 0; base < total2; base += T_MAPCAP) {
             wave_sync();
             {   // read lanes publish chunk -> read for this round
@@ -798,8 +820,108 @@ static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_
                               uint32_t phases, hipStream_t stream) {
     if (rd.n_reads == 0) return 0;
     const TileGrid tg = tile_grid(rd.n_reads, n_cu);
-    if (phases & 0x100u) k_tile<true><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases);
-    else k_tile<false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases);
+    const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
+    if (phases & 0x100u) k_tile<true, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, none);
+    else k_tile<false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, none);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Variant 3: the same work as three kernels, cut where the lane mapping changes, so that the
+// two phases that need little state (primer clips, window scan) run at a higher occupancy than
+// the fused kernel's 4 waves per SIMD:  k_trim (lane = read) -> k_scan (lane = chunk) ->
+// k_tile<SPLIT> (quality clip, outputs, counting).
+// ---------------------------------------------------------------------------------------
+constexpr int S_WAVES = 4;     // waves per block of k_trim / k_scan
+
+__global__ void __launch_bounds__(S_WAVES * 64)
+k_trim(KParams P, amp_dev_reads rd, DevOut out, SplitDesc sd) {
+    __shared__ uint32_t s_a[S_WAVES][T_MAXOPS * TILE], s_b[S_WAVES][T_MAXOPS * TILE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_u32 *const cigA = (lds_u32 *)s_a[wave], *const cigB = (lds_u32 *)s_b[wave];
+    const int64_t i = (int64_t)blockIdx.x * (S_WAVES * 64) + threadIdx.x;
+    if (i >= rd.n_reads) return;
+    const int32_t pos = rd.pos[i], tlen = rd.tlen[i], lseq = (int32_t)rd.lseq[i];
+    const uint32_t flag = rd.flag[i], c0 = rd.cig_off32[i], off8 = rd.seq_off8[i];
+    const int ncig = (int)(rd.cig_off32[i + 1] - c0);
+    const size_t slot = (size_t)c0 + 3 * (size_t)i;
+    const uint8_t *qual = rd.qual + (int64_t)off8 * 8;
+    const bool defer_full = ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u;
+    uint32_t meta = defer_full ? SD_DEFER : 0u, lohi = 0;
+    TrimState ts{pos, ncig, 0u, 0};
+    if (!defer_full) {
+        const bool have_qual = lseq > 0 && qual[0] != 0xFF;
+        LdsCig cur{cigA + lane}, tmp{cigB + lane};
+        int32_t qs = 0, lo = 0, qlen = 0;
+        bool can_q = false;
+        for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
+        if (P.do_trim) {
+            trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
+            if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);
+        }
+        if (!ts.err)
+            for (int k = 0; k < ts.n; ++k) out.new_cig[slot + k] = cur.get(k);
+        lohi = (uint32_t)lo | ((uint32_t)(lo + qlen) << 16);
+        meta = (uint32_t)(ts.n & 0xFF) | ((ts.flags & 0xFFu) << 8) | ((uint32_t)(ts.err & 0xFF) << 16) |
+               (have_qual ? SD_HAVE_QUAL : 0u) | (can_q ? SD_CAN_Q : 0u) | ((flag & 0x10u) ? SD_REV : 0u);
+    }
+    sd.pos[i] = ts.pos; sd.lohi[i] = lohi; sd.meta[i] = meta;
+}
+
+__global__ void __launch_bounds__(S_WAVES * 64)
+k_scan(KParams P, amp_dev_reads rd, SplitDesc sd, uint32_t phases) {
+    __shared__ uint32_t s_st[S_WAVES][S_WORDS * TILE];
+    __shared__ uint32_t s_map[S_WAVES][T_MAPCAP / 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_u32 *const st = (lds_u32 *)s_st[wave];
+    lds_u8 *const cmap = (lds_u8 *)s_map[wave];
+    const int64_t i = (int64_t)blockIdx.x * (S_WAVES * 64) + threadIdx.x;
+    const bool valid = i < rd.n_reads;
+    const int32_t Wd = P.window, mq = P.min_quality;
+    const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);
+    uint32_t meta = 0, lohi = 0, off8 = 0;
+    if (valid) { meta = sd.meta[i]; lohi = sd.lohi[i]; off8 = rd.seq_off8[i]; }
+    const int32_t lo = (int32_t)(lohi & 0xFFFFu), hi = (int32_t)(lohi >> 16);
+    const bool par_scan = valid && !(meta & SD_DEFER) && (meta & SD_CAN_Q) && Wd <= 8 && (phases & 2u);
+    uint32_t nch2 = 0;
+    if (par_scan && hi - lo >= Wd) nch2 = (uint32_t)(((hi - Wd) >> 3) - (lo >> 3) + 1);
+    uint32_t total2;
+    const uint32_t cb2 = wave_excl_scan(nch2, lane, total2);
+    st[S_OFF8 * TILE + lane] = off8;
+    st[S_LOHI * TILE + lane] = lohi;
+    st[S_FF * TILE + lane] = 0xFFFFu;
+    st[S_REV * TILE + lane] = (meta & SD_REV) ? 1u : 0u;
+    st[S_CB2 * TILE + lane] = cb2;
+    const ChunkEnv env{cmap, st, nullptr, nullptr, nullptr, rd.qual, rd.seq, nullptr, 0, 0u, (uint32_t)P.ref_len, mq};
+    for (uint32_t base = 0; base < total2; base += T_MAPCAP) {
+        wave_sync();
+        {
+            uint32_t a = cb2 > base ? cb2 : base, b = cb2 + nch2 < base + T_MAPCAP ? cb2 + nch2 : base + T_MAPCAP;
+            for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)lane;
+        }
+        wave_sync();
+        const uint32_t lim = total2 - base < (uint32_t)T_MAPCAP ? total2 - base : (uint32_t)T_MAPCAP;
+        const uint32_t thr = mqc * (uint32_t)Wd;
+        switch (Wd) {
+            case 1: p2_round<1>(env, lane, lim, base, thr); break; case 2: p2_round<2>(env, lane, lim, base, thr); break;
+            case 3: p2_round<3>(env, lane, lim, base, thr); break; case 4: p2_round<4>(env, lane, lim, base, thr); break;
+            case 5: p2_round<5>(env, lane, lim, base, thr); break; case 6: p2_round<6>(env, lane, lim, base, thr); break;
+            case 7: p2_round<7>(env, lane, lim, base, thr); break; default: p2_round<8>(env, lane, lim, base, thr); break;
+        }
+    }
+    wave_sync();
+    if (valid) sd.ff[i] = st[S_FF * TILE + lane];
+}
+
+static inline int split_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
+                               uint32_t *counts, const EventBuf &eb, uint32_t *dlist, uint32_t *dcnt, int n_cu,
+                               uint32_t phases, const SplitDesc &sd, hipStream_t stream) {
+    if (rd.n_reads == 0) return 0;
+    const TileGrid tg = tile_grid(rd.n_reads, n_cu);
+    const unsigned g1 = (unsigned)((rd.n_reads + S_WAVES * 64 - 1) / (S_WAVES * 64));
+    k_trim<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, out, sd);
+    if (P.do_trim && P.window <= 8 && (phases & 2u)) k_scan<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, sd, phases);
+    k_tile<false, true><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, sd);
     return (int)hipGetLastError();
 }
 

@@ -75,7 +75,7 @@ struct amp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timed = false;
     int n_cu = 256;
-    int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = tile kernel
+    int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
     uint32_t phases = 0xFFu;       // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
     char err[320] = {0};
@@ -780,7 +780,7 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
     const char *v = getenv("AMPLIHIP_KERNEL");
-    if (v && (v[0] == '1' || v[0] == '2')) c->kernel_variant = v[0] - '0';
+    if (v && v[0] >= '1' && v[0] <= '3') c->kernel_variant = v[0] - '0';
     v = getenv("AMPLIHIP_PHASES");
     if (v) c->phases = (uint32_t)strtoul(v, nullptr, 0);
     *out = c;
@@ -849,8 +849,8 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
     return AMP_OK;
 }
 
-int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = tile kernel
-    if (!c || (variant != 1 && variant != 2)) return AMP_EINVAL;
+int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline
+    if (!c || variant < 1 || variant > 3) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -897,11 +897,13 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
     const TileGrid tg = tile_grid(n, c->n_cu);
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 3 + (size_t)tg.grid * 6 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
     uint32_t *dcnt = dlist + (size_t)tg.grid * (size_t)tg.tpb * TILE;  // entries used in each segment
     uint32_t *extra = dcnt + tg.grid * 6 + 64;           // [grid] light counts | 64 | [4*grid] debug | [grid] heavy counts
+    SplitDesc sd{(int32_t *)extra, extra + n, extra + 2 * n, extra + 3 * n};      // variant 3 hand-over arrays
+    extra += 4 * n;
     c->dbg_dcnt = dcnt; c->dbg_grid = (int)tg.grid;
     if (c->phases & 0x100u) HIPCHK(c, hipMemsetAsync(dcnt, 0, ((size_t)tg.grid * 5 + 64) * 4, c->stream));
     if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
@@ -918,7 +920,9 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
     } else {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int rc = tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
+        int rc = c->kernel_variant == 3
+                     ? split_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, sd, c->stream)
+                     : tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         k_deferred_light<<<(unsigned)((tg.grid + 3) / 4), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,

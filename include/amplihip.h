@@ -207,8 +207,9 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
  * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short. */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 2 (default) = tile kernel; 1 = one-lane-per-read kernels, kept for on-GPU A/B checks.
- * Also settable with the environment variable AMPLIHIP_KERNEL. */
+/* 2 (default) = fused tile kernel; 1 = one-lane-per-read kernels and 3 = the same work cut into three
+ * kernels (k_trim, k_scan, k_tile<SPLIT>), both kept for on-GPU A/B checks (all three give identical
+ * results).  Also settable with the environment variable AMPLIHIP_KERNEL. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
 
 /* ---- calling: alleles_from_counts (AmpliPy.py:756-771) + the loop AmpliPy.py:917-952 --------

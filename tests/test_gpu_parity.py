@@ -12,7 +12,7 @@ from tests.gpu_util import GpuRunner, assert_same
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["lane_kernel", "tile_kernel"])
+@pytest.fixture(scope="module", params=[1, 2, 3], ids=["lane_kernel", "tile_kernel", "split_pipeline"])
 def runner(request):
     r = GpuRunner(variant=request.param)
     yield r
