@@ -24,7 +24,7 @@ from .insertions import EventStore
 VERSION = AMPLIPY_VERSION
 PROGRESS_NUM_READS = 50000          # AmpliPy.py:19
 BATCH_READS = 1 << 18              # reads per device batch on the Python-codec path (one Rec object each)
-NATIVE_BATCH_READS = 1 << 20       # records per device batch on the libampbam path (about 0.3 GB of host arrays at 150 bp)
+NATIVE_BATCH_READS = 1 << 18       # records per device batch on the libampbam path (the writer overlaps the next batch)
 
 DEFAULTS = dict(min_depth_consensus=10, min_depth_variants=1, min_freq_consensus=0, min_freq_variants=0.03,
                 min_length=30, min_quality=20, primer_pos_offset=0, sliding_window_width=4, unknown_symbol="N")
@@ -261,28 +261,57 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
         # re-encodes the kept ones; no per-read Python object exists on this path
         src, nwriter = native
-        for first in range(0, src.n_records, NATIVE_BATCH_READS):
-            count = min(NATIVE_BATCH_READS, src.n_records - first)
-            batch, _ = src.decode(first, count)
-            for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
-                if s_i:
-                    print_log("Processed %d reads..." % s_i)
-            s_i = first + count - 1
-            if batch.n == 0:
-                continue
-            res = eng.process(batch, read_base=read_base)
-            bad = np.nonzero(res.status)[0]
-            if len(bad):
-                _raise_for_status(res.status[bad[0]])
-            if run_trim and nwriter is not None:
-                keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
-                slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
-                nwriter.write_rows(batch.src_index, keep, res.new_pos, res.new_ncig, slot_off, res.new_cig)
-            if do_count:
-                ev = eng.events()
-                new = ev[ev["read"] >= read_base] if read_base else ev
-                ins_store.add(batch, new, read_base)
-            read_base += batch.n
+        # re-encoding + deflate is the longest stage: a writer thread takes batch k while this thread
+        # decodes and runs batch k+1 (every stage is a C call that releases the GIL; rows stay in order)
+        wq = werr = wthread = None
+        if run_trim and nwriter is not None:
+            import queue
+            import threading
+            wq = queue.Queue(maxsize=2); werr = []
+
+            def _writer():
+                while True:
+                    job = wq.get()
+                    if job is None:
+                        return
+                    if not werr:
+                        try:
+                            nwriter.write_rows(*job)
+                        except Exception as e:       # surfaced by the main thread
+                            werr.append(e)
+            wthread = threading.Thread(target=_writer, daemon=True); wthread.start()
+        try:
+            for first in range(0, src.n_records, NATIVE_BATCH_READS):
+                count = min(NATIVE_BATCH_READS, src.n_records - first)
+                batch, _ = src.decode(first, count)
+                for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
+                    if s_i:
+                        print_log("Processed %d reads..." % s_i)
+                s_i = first + count - 1
+                if batch.n == 0:
+                    continue
+                res = eng.process(batch, read_base=read_base)
+                bad = np.nonzero(res.status)[0]
+                if len(bad):
+                    _raise_for_status(res.status[bad[0]])
+                if wq is not None:
+                    if werr:
+                        raise werr[0]
+                    keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
+                    slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
+                    # src_index is a view of the decoder's buffers, which the next decode overwrites
+                    wq.put((batch.src_index.copy(), keep, res.new_pos, res.new_ncig, slot_off, res.new_cig))
+                if do_count:
+                    ev = eng.events()
+                    new = ev[ev["read"] >= read_base] if read_base else ev
+                    ins_store.add(batch, new, read_base)
+                read_base += batch.n
+        finally:
+            if wq is not None:
+                wq.put(None)
+                wthread.join()
+        if werr:
+            raise werr[0]
         if nwriter is not None:
             nwriter.close()
         src.close()

@@ -6,6 +6,10 @@
 #include "../../include/ampbam.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -193,18 +197,28 @@ int ampbam_open(const char *path, int n_threads, ampbam_file **out) {
     if (!f) return AMPBAM_ENOMEM;
     f->n_threads = pick_threads(n_threads);
     auto fail = [&](int rc, const char *msg) { (void)msg; delete f; return rc; };
-    FILE *fp = std::fopen(path, "rb");
-    if (!fp) return fail(AMPBAM_EIO, "open");
-    std::vector<uint8_t> raw;
-    try {
-        if (std::fseek(fp, 0, SEEK_END) != 0) { std::fclose(fp); return fail(AMPBAM_EIO, "seek"); }
-        const long sz = std::ftell(fp);
-        if (sz < 0) { std::fclose(fp); return fail(AMPBAM_EIO, "tell"); }
-        std::rewind(fp);
-        raw.resize((size_t)sz);
-        if (sz && std::fread(raw.data(), 1, (size_t)sz, fp) != (size_t)sz) { std::fclose(fp); return fail(AMPBAM_EIO, "read"); }
-    } catch (const std::bad_alloc &) { std::fclose(fp); return fail(AMPBAM_ENOMEM, "alloc"); }
-    std::fclose(fp);
+    // the compressed file is only read once, by the inflating workers: map it instead of copying it
+    struct Mapped {
+        const uint8_t *p = nullptr; size_t n = 0;
+        ~Mapped() { if (p && n) munmap(const_cast<uint8_t *>(p), n); }
+        const uint8_t *data() const { return p; }
+        size_t size() const { return n; }
+        const uint8_t &operator[](size_t i) const { return p[i]; }
+    } raw;
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(AMPBAM_EIO, "open");
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 0) { ::close(fd); return fail(AMPBAM_EIO, "stat"); }
+        raw.n = (size_t)st.st_size;
+        if (raw.n) {
+            void *m = mmap(nullptr, raw.n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); raw.n = 0; return fail(AMPBAM_EIO, "mmap"); }
+            raw.p = (const uint8_t *)m;
+            (void)madvise(m, raw.n, MADV_SEQUENTIAL);
+        }
+        ::close(fd);
+    }
 
     // ---- BGZF block table (serial hop over the headers) -----------------------------------
     std::vector<Block> blocks;
@@ -309,7 +323,6 @@ int ampbam_open(const char *path, int n_threads, ampbam_file **out) {
     } catch (const std::bad_alloc &) { bad = 1; for (auto &x : th) if (x.joinable()) x.join(); return fail(AMPBAM_ENOMEM, "alloc"); }
     for (auto &x : th) if (x.joinable()) x.join();
     if (bad) return fail(AMPBAM_EFORMAT, "inflate / CRC");
-    raw.clear(); raw.shrink_to_fit();
     f->rec_off.push_back(o);
     *out = f;
     return AMPBAM_OK;
