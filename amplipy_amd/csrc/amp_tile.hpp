@@ -42,7 +42,8 @@ constexpr int T_W = 512;          // reference positions covered by the LDS wind
 constexpr int T_MAXOPS = 8;       // CIGAR ops per read held in LDS (input ops <= T_MAXOPS-3)
 constexpr int T_MAPCAP = T_MAXOPS * TILE * 4;   // chunk-map bytes = the spare CIGAR buffer
 constexpr int T_SEGCAP = 128;     // match-op segments per tile
-constexpr int T_UNROLL = 4;       // chunks per lane whose loads are issued before any of them is processed
+constexpr int T_UNROLL = 3;       // chunks per lane whose loads are issued before any of them is processed (P2)
+constexpr int T_UNROLL4 = 3;      // ... in P4 (measured: 3 / 3 runs without register spills, 4 / 4 spills)
 constexpr int32_t NO_WINDOW = INT32_MIN;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -360,11 +361,11 @@ __device__ __forceinline__ void p2_round(const ChunkEnv &E, int lane, uint32_t l
 
 template <bool FULL>
 __device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t cc, uint32_t lim, uint32_t base) {
-    uint2 aq[T_UNROLL];
-    uint32_t as_[T_UNROLL], sgs[T_UNROLL];
-    int32_t jj[T_UNROLL];
+    uint2 aq[T_UNROLL4];
+    uint32_t as_[T_UNROLL4], sgs[T_UNROLL4];
+    int32_t jj[T_UNROLL4];
 #pragma unroll
-    for (int u = 0; u < T_UNROLL; ++u) {
+    for (int u = 0; u < T_UNROLL4; ++u) {
         const uint32_t c = cc + 64u * u;
         aq[u] = make_uint2(0, 0); as_[u] = 0; sgs[u] = 0; jj[u] = 0;
         if (FULL || c < lim) {
@@ -379,7 +380,7 @@ __device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t c
     }
     const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
 #pragma unroll
-    for (int u = 0; u < T_UNROLL; ++u) {
+    for (int u = 0; u < T_UNROLL4; ++u) {
         if (FULL || cc + 64u * u < lim) {
             const uint32_t sg = sgs[u];
             const uint32_t mm = E.seg[G_M * T_SEGCAP + sg];
@@ -453,7 +454,7 @@ __device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t c
 }
 
 __device__ __forceinline__ void p4_round(const ChunkEnv &E, int lane, uint32_t lim, uint32_t base) {
-    const uint32_t step = 64u * T_UNROLL;
+    const uint32_t step = 64u * T_UNROLL4;
     const uint32_t nfull = (lim / step) * step;
     uint32_t cc = (uint32_t)lane;
     for (; cc < nfull; cc += step) p4_block<true>(E, lane, cc, lim, base);
