@@ -808,9 +808,10 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 struct TileGrid { int64_t grid, tpb; };
 static inline TileGrid tile_grid(int64_t n_reads, int n_cu) {
     const int64_t n_tiles = (n_reads + TILE - 1) / TILE;
-    // eight blocks per CU: two are resident, the rest are handed out as CUs free up,
-    // which evens out the (measured) speed differences between XCDs
-    int64_t tpb = (n_tiles + 8 * (int64_t)n_cu - 1) / (8 * (int64_t)n_cu);
+    // 32 blocks per CU: two are resident, the rest are handed out as CUs free up, which evens out the
+    // (measured) speed differences between blocks and XCDs.  Measured on 19.9 M reads: 8 blocks per CU
+    // 3.45 ms, 16: 3.20, 32: 3.15, 64: 3.13, one tile per wave (the minimum): 3.34.
+    int64_t tpb = (n_tiles + 32 * (int64_t)n_cu - 1) / (32 * (int64_t)n_cu);
     tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;   // whole super-tiles per block
     if (tpb < T_WAVES) tpb = T_WAVES;
     return TileGrid{(n_tiles + tpb - 1) / tpb, tpb};
