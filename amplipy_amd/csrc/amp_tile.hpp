@@ -786,7 +786,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     if (n_err) atomicAdd(&ctr[2], n_err);
     if (tid == 0) {
         dcnt[blockIdx.x] = L.dcount; dcnt[5 * gridDim.x + 64 + blockIdx.x] = L.dcount2;
-        if (L.dcount + L.dcount2) atomicAdd(&ctr[3], (unsigned long long)(L.dcount + L.dcount2));
+        // (no per-block atomic on a shared counter here: thousands of blocks on one address serialise;
+        //  amp_debug_counters sums the per-block list counts instead)
     }
     if (stamps && lane == 0) {
         for (int k = 0; k < 6; ++k) atomicAdd(&ctr[8 + k], tacc[k]);

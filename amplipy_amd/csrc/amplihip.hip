@@ -1067,6 +1067,14 @@ int amp_debug_counters(amp_ctx *c, uint64_t *out16) {  // raw device counters (d
     Guard g(c);
     HIPCHK(c, hipMemcpyAsync(out16, c->d_ctr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->kernel_variant != 1 && c->dbg_dcnt && c->dbg_grid > 0) {      // [3]: deferred reads of the LAST batch, from the per-block list counts
+        std::vector<uint32_t> h((size_t)c->dbg_grid * 6 + 64);
+        HIPCHK(c, hipMemcpyAsync(h.data(), c->dbg_dcnt, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint64_t tot = 0;
+        for (int b = 0; b < c->dbg_grid; ++b) tot += (uint64_t)h[(size_t)b] + h[(size_t)c->dbg_grid * 5 + 64 + (size_t)b];
+        out16[3] = tot;
+    }
     return AMP_OK;
 }
 
