@@ -229,6 +229,26 @@ __device__ void flush_staged_events(const EventBuf &eb, const uint32_t *s_ev, ui
     __syncthreads();
 }
 
+// Sink of a read with a long CIGAR (tens of insertions): one reservation on the list cursor for the whole read
+// (an upper bound of its events) instead of one per event; slots left over are marked invalid
+// (ref_pos = -1) and dropped when the list is read out.  Counts go through the block's window.
+struct SliceSink {
+    WinSink &w;
+    amp_ins_event *slice;
+    uint32_t cap, used;
+    __device__ void add(int32_t r, uint32_t col) { w.add(r, col); }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+        if (used < cap) {
+            slice[used++] = amp_ins_event{pos, w.read, lo, hi};
+            const uint32_t d = (uint32_t)(pos - w.base);
+            if (d < D_WIN) lds_add(w.win + AMP_NSYM * D_WIN + d, 1u);
+            else atomicAdd(&w.eb.ins_at[pos], 1u);
+        } else {
+            w.event(pos, lo, hi);
+        }
+    }
+};
+
 struct NullSink {   // dry run: only the status matters
     __device__ void add(int32_t, uint32_t) {}
     __device__ void event(int32_t, int32_t, int32_t) {}
@@ -522,7 +542,31 @@ k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
                         s_coop[slot * 3 + 2] = (uint32_t)pf;
                     }
                 } else {
-                    process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, status_only);
+                    // longer CIGARs ping-pong in global memory; counts go through the block's window and the
+                    // events into a slice of the list reserved once for the read: its bound is the number of
+                    // bases on (q, None) pairs, i.e. of I / P / inner-S ops of the INPUT CIGAR (trimming only
+                    // turns such bases into clips)
+                    const size_t slot = (size_t)c0 + 3 * (size_t)i;
+                    uint32_t bound = 0;
+                    if (!status_only && P.do_count) {
+                        uint32_t lead = 0, all = 0, trail = 0;
+                        bool in_lead = true;
+                        for (int k = 0; k < n; ++k) {
+                            const uint32_t v = rd.cig[c0 + k], op = v & 15u, len = v >> 4;
+                            if (op == OP_H) continue;
+                            if (op == OP_S) { all += len; trail += len; if (in_lead) lead += len; }
+                            else { in_lead = false; trail = 0; if (op == OP_I || op == OP_P) all += len; }
+                        }
+                        bound = all - lead - (in_lead ? 0u : trail);
+                    }
+                    const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
+                    unsigned long long base0 = 0;
+                    if (bound) base0 = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)bound);
+                    const bool fits = bound && (long long)(base0 + bound) <= eb.cap;
+                    SliceSink ss{sink, eb.ev + (size_t)shard * (size_t)eb.cap + base0, fits ? bound : 0u, 0u};
+                    process_read_body(P, rd, i, out, ss, eb, status_only, CigBuf<1>{out.new_cig + slot}, CigBuf<1>{scratch + slot},
+                                      out.new_cig + slot, c0, n);
+                    for (uint32_t k = ss.used; k < ss.cap; ++k) ss.slice[k] = amp_ins_event{-1, 0u, 0, 0};
                 }
             }
         }
@@ -1048,6 +1092,10 @@ int amp_get_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap) 
             o += (int64_t)h[s];
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        int64_t w = 0;                                   // slots a read reserved and did not use carry ref_pos = -1
+        for (int64_t k = 0; k < total; ++k)
+            if (buf[k].ref_pos >= 0) { if (w != k) buf[w] = buf[k]; ++w; }
+        *n = w;
     }
     return AMP_OK;
 }

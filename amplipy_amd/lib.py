@@ -169,7 +169,7 @@ class Engine:
         if n.value:
             self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)),
                       "amp_get_ins_events")
-        return ev
+        return ev[:int(n.value)]          # the size query counts slots; a few may have been reserved and left unused
 
     def debug_blocks(self):
         out = np.zeros((4096, 4), np.uint32); nb = C.c_int(0)

@@ -188,7 +188,9 @@ int amp_last_kernel_ms(amp_ctx *ctx, float *total_ms, float *scan_ms);
 /* ---- accumulated state ----------------------------------------------------------------- */
 int amp_get_counts(amp_ctx *ctx, uint32_t *counts /* [ref_len][AMP_NSYM] host */);
 int amp_add_counts(amp_ctx *ctx, const uint32_t *counts /* host, added element-wise */);
-/* *n = number of events recorded so far; copies min(*n, cap) of them when buf != NULL. */
+/* buf == NULL: *n = an upper bound of the events recorded so far (list slots in use; reads with long
+ * CIGARs reserve a slice and may leave part of it unused).  buf != NULL (cap >= that bound): the events
+ * are copied and *n = their exact number. */
 int amp_get_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
 void *amp_counts_device_ptr(amp_ctx *ctx);
 /* Sum the device tables (counts + insertion tally) over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
