@@ -39,15 +39,16 @@ namespace amp {
 constexpr int TILE = 64;          // reads per wave tile
 constexpr int T_WAVES = 8;        // waves per block (two blocks per CU)
 constexpr int T_W = 512;          // reference positions covered by the LDS window
-constexpr int T_MAXOPS = 8;       // CIGAR ops per read held in LDS (input ops <= T_MAXOPS-3)
-constexpr int T_MAPCAP = T_MAXOPS * TILE * 4;   // chunk-map bytes = the spare CIGAR buffer
-constexpr int T_SEGCAP = 128;     // match-op segments per tile
+constexpr int T_MAXOPS = 18;      // CIGAR ops per read held in LDS as 16-bit words (input ops <= T_MAXOPS-3, lengths sum < 4096)
+constexpr int T_MAPCAP = T_MAXOPS * TILE * 2;   // chunk-map bytes = the spare CIGAR buffer
+constexpr int T_SEGCAP = 192;     // match-op segments per tile
 constexpr int T_UNROLL = 3;       // chunks per lane whose loads are issued before any of them is processed (P2)
 constexpr int T_UNROLL4 = 3;      // ... in P4 (measured: 3 / 3 runs without register spills, 4 / 4 spills)
 constexpr int32_t NO_WINDOW = INT32_MIN;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // entries of the deferred list: read index | kind
 constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;   // counted by the tile kernel; only the exact status is missing
@@ -56,11 +57,11 @@ constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 
 // per-read state words kept in LDS for the chunk lanes
 enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_WORDS };
-enum : int { G_OFF8, G_M, G_R0, G_RC, G_WORDS };   // per-segment words; G_RC = owner lane | chunk base << 8
+enum : int { G_M, G_R0, G_RC, G_WORDS };   // per-segment words; G_RC = owner lane | chunk base << 8 (the read's offset is st[S_OFF8][lane])
 
 struct WaveLds {
-    uint32_t cigA[T_MAXOPS * TILE];
-    uint32_t cigB[T_MAXOPS * TILE];   // scratch during trimming, chunk map during P2 / P4
+    uint16_t cigA[T_MAXOPS * TILE];   // len<<4|op in 16 bits: the tile path takes reads whose op lengths sum to < 4096
+    uint16_t cigB[T_MAXOPS * TILE];   // scratch during trimming, chunk map during P2 / P4
     uint32_t st[S_WORDS * TILE];
     uint32_t seg[G_WORDS * T_SEGCAP];
 };
@@ -74,9 +75,9 @@ struct BlockLds {
 
 // one CIGAR column in LDS (stride TILE words)
 struct LdsCig {
-    lds_u32 *p;
+    lds_u16 *p;
     __device__ __forceinline__ uint32_t get(int i) const { return p[i * TILE]; }
-    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * TILE] = v; }
+    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i * TILE] = (uint16_t)v; }
 };
 
 // Lanes of one wave hand data to each other through LDS only: the fences are restricted to the local
@@ -372,7 +373,7 @@ __device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t c
             const uint32_t sg = E.cmap[c];
             const int32_t m0 = (int32_t)(E.seg[G_M * T_SEGCAP + sg] & 0xFFFFu);
             const int32_t j0 = ((int32_t)(c + base - (E.seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
-            const int64_t rb = (int64_t)E.seg[G_OFF8 * T_SEGCAP + sg] * 8 + j0;
+            const int64_t rb = (int64_t)E.st[S_OFF8 * TILE + (E.seg[G_RC * T_SEGCAP + sg] & 0xFFu)] * 8 + j0;
             aq[u] = *(const uint2 *)(E.qual + rb);
             as_[u] = *(const uint32_t *)(E.seq + (rb >> 1));
             sgs[u] = sg; jj[u] = j0;
@@ -493,8 +494,8 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     int32_t win_base = NO_WINDOW;
     lds_u32 *const st = (lds_u32 *)L.wv[wave].st;
     lds_u32 *const seg = (lds_u32 *)L.wv[wave].seg;
-    lds_u32 *const cigA = (lds_u32 *)L.wv[wave].cigA;
-    lds_u32 *const cigB = (lds_u32 *)L.wv[wave].cigB;
+    lds_u16 *const cigA = (lds_u16 *)L.wv[wave].cigA;
+    lds_u16 *const cigB = (lds_u16 *)L.wv[wave].cigB;
     lds_u8 *const cmap = (lds_u8 *)L.wv[wave].cigB;
     TileCtx tc{win, 0, 0u, counts, eb, (uint32_t)P.ref_len};
     const int32_t mq = P.min_quality;
@@ -551,11 +552,18 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const int64_t boff = (int64_t)off8 * 8;
         const uint8_t *qual = rd.qual + boff;
         bool defer_full = SPLIT ? (meta & SD_DEFER) != 0 : valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
+        LdsCig cur{cigA + lane}, tmp{cigB + lane};
+        if (!SPLIT && valid && !defer_full) {
+            // the columns hold len<<4|op in 16 bits: a read takes the tile path when no length a trim could
+            // produce (ops merge, clips add up) reaches 4096, i.e. when all its lengths sum to less
+            uint32_t sumlen = 0;
+            for (int k = 0; k < ncig; ++k) { const uint32_t w = rd.cig[c0 + k]; cur.set(k, w); sumlen += w >> 4; }
+            if (sumlen >= 4096u) defer_full = true;
+        }
         const bool mine = valid && !defer_full;
         const bool have_qual = SPLIT ? (meta & SD_HAVE_QUAL) != 0 : mine && lseq > 0 && qual[0] != 0xFF;
         const bool rev = SPLIT ? (meta & SD_REV) != 0 : (flag & 0x10u) != 0;
         TrimState ts{pos, ncig, 0u, 0};
-        LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
         bool can_q = false;
         if (SPLIT) {
@@ -566,12 +574,11 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (mine && !ts.err)
                 for (int k = 0; k < ts.n; ++k) cur.set(k, out.new_cig[slot + k]);
         } else if (mine) {
-            for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
             if (P.do_trim) {
                 trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
                 if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);
                 if (cur.p != cigA + lane) {           // keep the CIGAR in buffer A: B becomes the chunk map
-                    for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = cur.get(k);
+                    for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = (uint16_t)cur.get(k);
                     cur.p = cigA + lane; tmp.p = cigB + lane;
                 }
             }
@@ -649,7 +656,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
             trim_quality_apply(ts, rev, iq, qlen, qs, cur, tmp);
             if (!ts.err && cur.p != cigA + lane) {
-                for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = cur.get(k);
+                for (int k = 0; k < ts.n; ++k) cigA[lane + k * TILE] = (uint16_t)cur.get(k);
                 cur.p = cigA + lane; tmp.p = cigB + lane;
             }
         }
@@ -688,13 +695,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 int32_t len = (int32_t)(v >> 4);
                 if (is_match_op(op)) {
                     if (len > 0) {
-                        seg[G_OFF8 * T_SEGCAP + sidx] = off8;
                         seg[G_M * T_SEGCAP + sidx] = (uint32_t)q | ((uint32_t)(q + len) << 16);
                         seg[G_R0 * T_SEGCAP + sidx] = (uint32_t)r;
                         seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
                         nch4 += (uint32_t)(((q + len + 7) >> 3) - (q >> 3));
                     } else {
-                        seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_OFF8 * T_SEGCAP + sidx] = off8; seg[G_R0 * T_SEGCAP + sidx] = 0u;
+                        seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_R0 * T_SEGCAP + sidx] = 0u;
                         seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
                     }
                     ++sidx;
@@ -839,9 +845,9 @@ constexpr int S_WAVES = 4;     // waves per block of k_trim / k_scan
 
 __global__ void __launch_bounds__(S_WAVES * 64)
 k_trim(KParams P, amp_dev_reads rd, DevOut out, SplitDesc sd) {
-    __shared__ uint32_t s_a[S_WAVES][T_MAXOPS * TILE], s_b[S_WAVES][T_MAXOPS * TILE];
+    __shared__ uint16_t s_a[S_WAVES][T_MAXOPS * TILE], s_b[S_WAVES][T_MAXOPS * TILE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    lds_u32 *const cigA = (lds_u32 *)s_a[wave], *const cigB = (lds_u32 *)s_b[wave];
+    lds_u16 *const cigA = (lds_u16 *)s_a[wave], *const cigB = (lds_u16 *)s_b[wave];
     const int64_t i = (int64_t)blockIdx.x * (S_WAVES * 64) + threadIdx.x;
     if (i >= rd.n_reads) return;
     const int32_t pos = rd.pos[i], tlen = rd.tlen[i], lseq = (int32_t)rd.lseq[i];
@@ -849,15 +855,19 @@ k_trim(KParams P, amp_dev_reads rd, DevOut out, SplitDesc sd) {
     const int ncig = (int)(rd.cig_off32[i + 1] - c0);
     const size_t slot = (size_t)c0 + 3 * (size_t)i;
     const uint8_t *qual = rd.qual + (int64_t)off8 * 8;
-    const bool defer_full = ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u;
+    bool defer_full = ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u;
+    LdsCig cur{cigA + lane}, tmp{cigB + lane};
+    if (!defer_full) {
+        uint32_t sumlen = 0;
+        for (int k = 0; k < ncig; ++k) { const uint32_t w = rd.cig[c0 + k]; cur.set(k, w); sumlen += w >> 4; }
+        if (sumlen >= 4096u) defer_full = true;
+    }
     uint32_t meta = defer_full ? SD_DEFER : 0u, lohi = 0;
     TrimState ts{pos, ncig, 0u, 0};
     if (!defer_full) {
         const bool have_qual = lseq > 0 && qual[0] != 0xFF;
-        LdsCig cur{cigA + lane}, tmp{cigB + lane};
         int32_t qs = 0, lo = 0, qlen = 0;
         bool can_q = false;
-        for (int k = 0; k < ncig; ++k) cur.set(k, rd.cig[c0 + k]);
         if (P.do_trim) {
             trim_primers(P, ts, flag, tlen, lseq, cur, tmp);
             if (!ts.err) can_q = quality_window(ts, lseq, have_qual, cur, qs, lo, qlen);

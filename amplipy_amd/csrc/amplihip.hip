@@ -1119,9 +1119,10 @@ int amp_debug_counters(amp_ctx *c, uint64_t *out16) {  // raw device counters (d
         std::vector<uint32_t> h((size_t)c->dbg_grid * 6 + 64);
         HIPCHK(c, hipMemcpyAsync(h.data(), c->dbg_dcnt, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        uint64_t tot = 0;
-        for (int b = 0; b < c->dbg_grid; ++b) tot += (uint64_t)h[(size_t)b] + h[(size_t)c->dbg_grid * 5 + 64 + (size_t)b];
-        out16[3] = tot;
+        uint64_t tot = 0, heavy = 0;
+        for (int b = 0; b < c->dbg_grid; ++b) { tot += h[(size_t)b]; heavy += h[(size_t)c->dbg_grid * 5 + 64 + (size_t)b]; }
+        out16[3] = tot + heavy;
+        out16[0] = heavy;                         // [0]: of which heavy entries (whole read / exact status)
     }
     return AMP_OK;
 }

@@ -14,7 +14,7 @@ mn, mx, mpl = lib.find_overlapping_primers(g.size, pr, 0)
 e = lib.Engine(g.size); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
 for it in range(3):
     e.reset(); e.process(b, want_trim=False); tot, scan = e.last_kernel_ms()
-    print("iter %d: kernels %.3f ms (tile %.3f) -> %.1f Mreads/s, %.2f Gbases/s; deferred=%d" % (it, tot, scan, b.n / tot / 1e3, b.total_bases() / tot / 1e6, e.debug_counters()[3]))
+    print("iter %d: kernels %.3f ms (tile %.3f) -> %.1f Mreads/s, %.2f Gbases/s; deferred=%d (heavy %d)" % (it, tot, scan, b.n / tot / 1e3, b.total_bases() / tot / 1e6, e.debug_counters()[3], e.debug_counters()[0]))
 base = ReadBatch.from_segments(pool)
 e.reset(); e.process(base, want_trim=False); c1 = e.counts()
 e.reset(); e.process(b, want_trim=False); cN = e.counts()
