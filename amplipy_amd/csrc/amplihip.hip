@@ -455,13 +455,14 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
     __shared__ uint32_t s_ev[4 * D_EVCAP];
     __shared__ uint32_t s_nev;
     __shared__ unsigned long long s_evbase;
-    // one wave per list segment, four segments per block (a segment rarely fills a whole block)
-    const int64_t sb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u;
+    // half a block (128 lanes) per list segment, D_LSEG segments per block (a segment rarely fills a whole block)
+    constexpr int D_LSEG = 2, D_LLANES = 256 / D_LSEG;
+    const int64_t sb = (int64_t)blockIdx.x * D_LSEG + (threadIdx.x / D_LLANES);
+    const uint32_t lane = threadIdx.x % D_LLANES;
     const uint32_t cnt = sb < n_seg ? dcnt[sb] : 0u;
     uint32_t cmax = 0;
-    for (int w = 0; w < 4; ++w) {
-        const int64_t s2 = (int64_t)blockIdx.x * 4 + w;
+    for (int w = 0; w < D_LSEG; ++w) {
+        const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w;
         const uint32_t c2 = s2 < n_seg ? dcnt[s2] : 0u;
         cmax = c2 > cmax ? c2 : cmax;
     }
@@ -469,7 +470,7 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
     const uint32_t *seg = dlist + (size_t)sb * (size_t)tiles_per_block * TILE;
     if (threadIdx.x == 0) s_nev = 0;
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < cmax; k0 += 64) {
+    for (uint32_t k0 = 0; k0 < cmax; k0 += D_LLANES) {
         const uint32_t k = k0 + lane;
         if (k < cnt) {
             const int64_t i = (int64_t)(seg[k] & DEFER_INDEX_MASK);
@@ -969,7 +970,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
                      : tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_deferred_light<<<(unsigned)((tg.grid + 3) / 4), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
+        k_deferred_light<<<(unsigned)((tg.grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
                                                                                (long long)tg.tpb, (long long)tg.grid);
         HIPCHK(c, hipGetLastError());
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
