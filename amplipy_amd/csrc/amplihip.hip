@@ -466,6 +466,11 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
         const uint32_t c2 = s2 < n_seg ? dcnt[s2] : 0u;
         cmax = c2 > cmax ? c2 : cmax;
     }
+    if (threadIdx.x == 0) {      // tell the heavy pass whether it has anything to do at all (ctr[24], sticky until amp_reset)
+        uint32_t hv = 0;
+        for (int w = 0; w < D_LSEG; ++w) { const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w; if (s2 < n_seg) hv |= dcnt[5 * n_seg + 64 + s2]; }
+        if (hv) atomicOr(&eb.ctr[24], 1ull);
+    }
     if (cmax == 0) return;
     const uint32_t *seg = dlist + (size_t)sb * (size_t)tiles_per_block * TILE;
     if (threadIdx.x == 0) s_nev = 0;
@@ -485,43 +490,81 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
 // Heavy half, off the back of the segment: reads the tile kernel could not take at all (more CIGAR ops
 // than its LDS column, unusual CIGAR, no room in the tile's segment table) and reads that need
 // their exact status.  Lane = read for trimming and indels, lane groups for match bases.
-__global__ void __launch_bounds__(256)
-k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
-    __shared__ uint32_t s_cig[2 * D_MAXOPS * 256];
-    __shared__ uint32_t s_win[D_PLANES * D_WIN];
-    __shared__ uint32_t s_coop[3 * 256];
-    __shared__ uint32_t s_ev[4 * D_EVCAP];
-    __shared__ uint32_t s_ncoop, s_nev;
-    __shared__ unsigned long long s_evbase;
-    // Few reads are heavy: a small persistent grid looks at 64 segment counts per wave-load and only
-    // enters segments that have entries (a block per segment would cost more in empty launches).
-    __shared__ unsigned long long s_mask;
-    for (int64_t sb0 = blockIdx.x; sb0 < n_seg; sb0 += (int64_t)gridDim.x * 64) {
+// The work item of a block is a UNIT of D_UNIT consecutive list segments (neighbours on the reference, so
+// they can share one LDS window).  SPARSE = true takes the units with at most one round of entries in all and
+// runs them as ONE round (a few heavy reads per segment are the common case, and a round per
+// segment would be all latency); SPARSE = false takes the other units segment by segment, so that
+// a batch made of heavy reads keeps one block per segment.
+constexpr int D_UNIT = 8;
+struct HeavyLds {
+    uint32_t cig[2 * D_MAXOPS * 256];
+    uint32_t win[D_PLANES * D_WIN];
+    uint32_t coop[3 * 256];
+    uint32_t ev[4 * D_EVCAP];
+    uint32_t ucnt[D_UNIT + 1];
+    uint32_t ncoop, nev;
+    unsigned long long evbase, mask;
+};
+
+template <bool SPARSE>
+__device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
+                                           uint32_t *scratch, uint32_t *counts, const EventBuf &eb, const uint32_t *dlist,
+                                           const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
+    uint32_t *const s_cig = L.cig, *const s_win = L.win, *const s_coop = L.coop, *const s_ev = L.ev, *const s_ucnt = L.ucnt;
+    uint32_t &s_ncoop = L.ncoop, &s_nev = L.nev;
+    unsigned long long &s_evbase = L.evbase, &s_mask = L.mask;
+    // Few reads are heavy: a small persistent grid looks at the counts of 64 work items per wave-load and only
+    // enters those that have entries (a block per segment would cost more in empty launches).
+    // work items: whole units (SPARSE) or single segments of the other units
+    const int64_t n_item = SPARSE ? (n_seg + D_UNIT - 1) / D_UNIT : n_seg;
+    for (int64_t u0 = blockIdx.x; u0 < n_item; u0 += (int64_t)gridDim.x * 64) {
     if (threadIdx.x < 64) {
-        const int64_t sbl = sb0 + (int64_t)threadIdx.x * gridDim.x;
-        const unsigned long long mk = __ballot(sbl < n_seg && dcnt[5 * n_seg + 64 + sbl] != 0);
+        const int64_t it = u0 + (int64_t)threadIdx.x * gridDim.x;
+        uint32_t tot = 0, own = 0;
+        if (it < n_item) {
+            const int64_t unit = SPARSE ? it : it / D_UNIT;
+            for (int j = 0; j < D_UNIT; ++j) { const int64_t sbj = unit * D_UNIT + j; if (sbj < n_seg) tot += dcnt[5 * n_seg + 64 + sbj]; }
+            own = SPARSE ? tot : dcnt[5 * n_seg + 64 + it];
+        }
+        const unsigned long long mk = __ballot(own != 0 && (tot <= 256u) == SPARSE);
         if (threadIdx.x == 0) s_mask = mk;
     }
     __syncthreads();
     unsigned long long todo = s_mask;
     __syncthreads();
     while (todo) {
-    const int64_t sb = sb0 + (int64_t)(__ffsll((long long)todo) - 1) * gridDim.x;
+    const int64_t item = u0 + (int64_t)(__ffsll((long long)todo) - 1) * gridDim.x;
     todo &= todo - 1;
-    const uint32_t cnt = dcnt[5 * n_seg + 64 + sb];
-    const uint32_t *seg_end = dlist + ((size_t)sb + 1) * (size_t)tiles_per_block * TILE;
+    {
+    const int64_t sb_first = SPARSE ? item * D_UNIT : item;
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // exclusive prefix of the pass's segment counts
+        uint32_t acc = 0;
+        for (int j = 0; j < D_UNIT; ++j) {
+            s_ucnt[j] = acc;
+            const int64_t sbj = sb_first + j;
+            if (sbj < n_seg && (SPARSE || j == 0)) acc += dcnt[5 * n_seg + 64 + sbj];
+        }
+        s_ucnt[D_UNIT] = acc;
+        s_ncoop = 0; s_nev = 0;
+    }
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
-    if (threadIdx.x == 0) { s_ncoop = 0; s_nev = 0; }
-    // sorted input: no read of this segment starts left of the first read of its tile range
-    int32_t base = rd.pos[sb * tiles_per_block * TILE];
+    // sorted input: no read of this pass starts left of the first read of its first tile range
+    int32_t base = rd.pos[sb_first * tiles_per_block * TILE];
     if (base < 0) base = 0;
     __syncthreads();
+    const uint32_t cnt = s_ucnt[D_UNIT];
     uint32_t done = 0;   // cooperative entries of earlier rounds (the LDS cursor keeps counting)
     for (uint32_t k0 = 0; k0 < cnt; k0 += blockDim.x) {
         const uint32_t k = k0 + threadIdx.x;
         if (k < cnt) {
-            const uint32_t e = seg_end[-1 - (int64_t)k];
+            int j = 0;
+            if (SPARSE) {
+#pragma unroll
+                for (int jj = 1; jj < D_UNIT; ++jj) j += k >= s_ucnt[jj] ? 1 : 0;
+            }
+            const uint32_t *seg_end = dlist + ((size_t)(sb_first + j) + 1) * (size_t)tiles_per_block * TILE;
+            const uint32_t e = seg_end[-1 - (int64_t)(k - s_ucnt[j])];
             const int64_t i = (int64_t)(e & DEFER_INDEX_MASK);
             bool status_only = (e & DEFER_STATUS_ONLY) != 0, more = true;
             WinSink sink{(lds_u32 *)s_win, base, counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
@@ -591,8 +634,21 @@ k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
         else atomicAdd(&eb.ins_at[p], v);
     }
     __syncthreads();
-    }   // segments of this round
+    }
+    }   // items of this round
     }   // rounds
+}
+
+// one launch for both kinds of work item: an empty launch is not free when the other step's scan
+// kernel holds the LDS of every CU
+__global__ void __launch_bounds__(256)
+k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
+    __shared__ HeavyLds L;
+    if (__hip_atomic_load(&eb.ctr[24], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // set by k_deferred_light
+    heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg);
+    __syncthreads();
+    heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg);
 }
 
 __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
