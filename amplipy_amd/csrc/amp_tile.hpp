@@ -315,20 +315,31 @@ __device__ __forceinline__ void p2_block(const ChunkEnv &E, uint32_t cc, uint32_
     uint2 a0[T_UNROLL], a1[T_UNROLL];
     uint32_t rr[T_UNROLL];
     int32_t jj[T_UNROLL];
+    // every address of the block first, then its loads back to back: a load issued between the address
+    // computations of the next chunk gets waited for as soon as the compiler reuses one of its registers
+    const uint8_t *qp[T_UNROLL];
 #pragma unroll
     for (int u = 0; u < T_UNROLL; ++u) {
         const uint32_t c = cc + 64u * u;
-        a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0); rr[u] = 0; jj[u] = 0;
+        rr[u] = 0; jj[u] = 0; qp[u] = E.qual;
         if (FULL || c < lim) {
             const uint32_t r = E.cmap[c];
             const int32_t rlo = (int32_t)(E.st[S_LOHI * TILE + r] & 0xFFFFu);
             const int32_t j0 = ((int32_t)(c + base - E.st[S_CB2 * TILE + r]) + (rlo >> 3)) * 8;
-            const uint8_t *qp = E.qual + (int64_t)E.st[S_OFF8 * TILE + r] * 8 + j0;
-            a0[u] = *(const uint2 *)qp;
-            a1[u] = *(const uint2 *)(qp + 8);
+            qp[u] = E.qual + (int64_t)E.st[S_OFF8 * TILE + r] * 8 + j0;
             rr[u] = r; jj[u] = j0;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < T_UNROLL; ++u) {
+        a0[u] = make_uint2(0, 0); a1[u] = make_uint2(0, 0);
+        if (FULL || cc + 64u * u < lim) {
+            a0[u] = *(const uint2 *)qp[u];
+            a1[u] = *(const uint2 *)(qp[u] + 8);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < T_UNROLL; ++u) {
         if (FULL || cc + 64u * u < lim) {
@@ -365,20 +376,29 @@ __device__ __forceinline__ void p4_block(const ChunkEnv &E, int lane, uint32_t c
     uint2 aq[T_UNROLL4];
     uint32_t as_[T_UNROLL4], sgs[T_UNROLL4];
     int32_t jj[T_UNROLL4];
+    int64_t rbs[T_UNROLL4];
 #pragma unroll
-    for (int u = 0; u < T_UNROLL4; ++u) {
+    for (int u = 0; u < T_UNROLL4; ++u) {      // addresses first, loads back to back (see p2_block)
         const uint32_t c = cc + 64u * u;
-        aq[u] = make_uint2(0, 0); as_[u] = 0; sgs[u] = 0; jj[u] = 0;
+        sgs[u] = 0; jj[u] = 0; rbs[u] = 0;
         if (FULL || c < lim) {
             const uint32_t sg = E.cmap[c];
             const int32_t m0 = (int32_t)(E.seg[G_M * T_SEGCAP + sg] & 0xFFFFu);
             const int32_t j0 = ((int32_t)(c + base - (E.seg[G_RC * T_SEGCAP + sg] >> 8)) + (m0 >> 3)) * 8;
-            const int64_t rb = (int64_t)E.st[S_OFF8 * TILE + (E.seg[G_RC * T_SEGCAP + sg] & 0xFFu)] * 8 + j0;
-            aq[u] = *(const uint2 *)(E.qual + rb);
-            as_[u] = *(const uint32_t *)(E.seq + (rb >> 1));
+            rbs[u] = (int64_t)E.st[S_OFF8 * TILE + (E.seg[G_RC * T_SEGCAP + sg] & 0xFFu)] * 8 + j0;
             sgs[u] = sg; jj[u] = j0;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < T_UNROLL4; ++u) {
+        aq[u] = make_uint2(0, 0); as_[u] = 0;
+        if (FULL || cc + 64u * u < lim) {
+            aq[u] = *(const uint2 *)(E.qual + rbs[u]);
+            as_[u] = *(const uint32_t *)(E.seq + (rbs[u] >> 1));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const uint32_t rot = ((uint32_t)lane >> 2) & 7u;
 #pragma unroll
     for (int u = 0; u < T_UNROLL4; ++u) {
