@@ -573,15 +573,29 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const uint8_t *qual = rd.qual + boff;
         bool defer_full = SPLIT ? (meta & SD_DEFER) != 0 : valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
-        if (!SPLIT && valid && !defer_full) {
+        uint32_t q0 = 0xFFu;
+        if (!SPLIT) {
+            // second level of loads, all issued before any is waited for: the first quality byte (QUAL '*' marker)
+            // and every CIGAR word of the tile (a loop over k with a load and a wait per turn made this
+            // several dependent round trips)
+            const bool ld = valid && !defer_full;
+            int maxn = ld ? ncig : 0;
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxn, o); maxn = t > maxn ? t : maxn; }
+            uint32_t w[T_MAXOPS - 3];
+#pragma unroll
+            for (int k = 0; k < T_MAXOPS - 3; ++k) { w[k] = 0; if (k < maxn && ld && k < ncig) w[k] = rd.cig[c0 + k]; }
+            if (ld && lseq > 0) q0 = qual[0];
+            __builtin_amdgcn_sched_barrier(0);
             // the columns hold len<<4|op in 16 bits: a read takes the tile path when no length a trim could
             // produce (ops merge, clips add up) reaches 4096, i.e. when all its lengths sum to less
             uint32_t sumlen = 0;
-            for (int k = 0; k < ncig; ++k) { const uint32_t w = rd.cig[c0 + k]; cur.set(k, w); sumlen += w >> 4; }
+#pragma unroll
+            for (int k = 0; k < T_MAXOPS - 3; ++k)
+                if (k < maxn && ld && k < ncig) { cur.set(k, w[k]); sumlen += w[k] >> 4; }
             if (sumlen >= 4096u) defer_full = true;
         }
         const bool mine = valid && !defer_full;
-        const bool have_qual = SPLIT ? (meta & SD_HAVE_QUAL) != 0 : mine && lseq > 0 && qual[0] != 0xFF;
+        const bool have_qual = SPLIT ? (meta & SD_HAVE_QUAL) != 0 : mine && lseq > 0 && q0 != 0xFFu;
         const bool rev = SPLIT ? (meta & SD_REV) != 0 : (flag & 0x10u) != 0;
         TrimState ts{pos, ncig, 0u, 0};
         int32_t qs = 0, lo = 0, qlen = 0;
