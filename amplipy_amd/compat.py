@@ -1,0 +1,84 @@
+"""The reference's per-read function seams on top of the batch ABI:
+
+    trim_read(s, min_primer_start, max_primer_end, max_primer_len, min_quality, sliding_window_width)
+        -> (trimmed_primer_start, trimmed_primer_end, trimmed_quality), mutating ``s``      AmpliPy.py:426, :907
+    update_base_counts(symbol_counts_at_ref_pos, s, min_quality)                            AmpliPy.py:690, :915
+    alleles_from_counts(symbol_counts) -> (total, [(count, freq, symbol), ...])             AmpliPy.py:756, :925
+    find_overlapping_primers(ref_genome_len, primers, primer_pos_offset)                    AmpliPy.py:174
+
+A call per read through an FFI costs far more than the work (the drop-in boundary is the
+batch), so this module is for code and tests written against the reference's function signatures, not for
+throughput: every call packs ONE read and runs it through the GPU library.  ``s`` is any object with the
+pysam.AlignedSegment attributes the reference touches (amplipy_amd.segment.Segment is one); errors are
+raised as the exception class the reference raises on the same read.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi, lib
+from .batch import ReadBatch
+from .insertions import event_strings
+
+_ENGINES = {}
+
+
+def _engine(ref_len):
+    e = _ENGINES.get(ref_len)
+    if e is None:
+        e = _ENGINES[ref_len] = lib.Engine(ref_len)
+    return e
+
+
+def _table(lst):
+    return np.array([-1 if v is None else int(v) for v in lst], np.int32)
+
+
+def _raise(status):
+    exc = abi.READ_STATUS_EXC[int(status)]
+    if exc is not None:
+        raise exc("amplihip read status %d" % int(status))
+
+
+def find_overlapping_primers(ref_genome_len, primers, primer_pos_offset):
+    """(min_primer_start, max_primer_end): lists of length ref_genome_len with None where no primer overlaps."""
+    mn, mx, _ = lib.find_overlapping_primers(ref_genome_len, primers, primer_pos_offset)
+    return [None if v < 0 else int(v) for v in mn], [None if v < 0 else int(v) for v in mx]
+
+
+def trim_read(s, min_primer_start, max_primer_end, max_primer_len, min_quality, sliding_window_width):
+    G = len(min_primer_start)
+    e = _engine(G)
+    e.reset()
+    e.set_primers(_table(min_primer_start), _table(max_primer_end), int(max_primer_len))
+    e.set_params(int(min_quality), int(sliding_window_width), True, False)
+    res = e.process(ReadBatch.from_segments([s]))
+    _raise(res.status[0])
+    s.cigartuples = res.cigar_ops(0)
+    s.reference_start = int(res.new_pos[0])
+    f = int(res.trim_flags[0])
+    return bool(f & 1), bool(f & 2), bool(f & 4)
+
+
+def update_base_counts(symbol_counts_at_ref_pos, s, min_quality):
+    G = len(symbol_counts_at_ref_pos)
+    e = _engine(G)
+    e.reset()
+    e.set_params(int(min_quality), 4, False, True)
+    batch = ReadBatch.from_segments([s])
+    res = e.process(batch)
+    _raise(res.status[0])
+    counts = e.counts()
+    for p, c in np.argwhere(counts):
+        d = symbol_counts_at_ref_pos[int(p)]
+        k = abi.SYMBOLS[int(c)]
+        d[k] = d.get(k, 0) + int(counts[p, c])
+    for pos, text in event_strings(batch, e.events()):
+        d = symbol_counts_at_ref_pos[pos]
+        d[text] = d.get(text, 0) + 1                                     # AmpliPy.py:745-748
+
+
+def alleles_from_counts(symbol_counts):
+    """Total count and the alleles with a non-zero count as (count, frequency, symbol), largest tuple first."""
+    total = sum(symbol_counts.values())
+    return total, sorted(((c, c / total, k) for k, c in symbol_counts.items() if c != 0), reverse=True)

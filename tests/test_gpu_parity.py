@@ -375,3 +375,40 @@ def test_one_very_long_read(runner):
     good = ReadBatch.from_segments([segs[i] for i in ok])
     assert int(good.lseq.max()) == L
     assert_same(oracle.process(good, G, mn, mx, 30, 20, 4), runner.process(good, G, mn, mx, 30, 20, 4), good)
+
+
+def test_function_level_seams_replay_the_named_cases():
+    """amplipy_amd.compat: trim_read / update_base_counts / alleles_from_counts / find_overlapping_primers with
+    the reference's own signatures, replayed on golden named cases (one GPU call per read)."""
+    from collections import Counter
+    from amplipy_amd import compat
+    cases = H.load_json("named_cases.json")["cases"]
+    n_checked = 0
+    for case in cases:
+        G = case["ref_len"]
+        mn, mx = compat.find_overlapping_primers(G, [tuple(p) for p in case["primers"]], case["offset"])
+        assert len(mn) == G and all(v is None or isinstance(v, int) for v in mn[:50])
+        for rd, exp in list(zip(case["reads"], case["expected"]))[:8]:
+            t = exp["trim"]
+            s = H.seg_from_dict(rd)
+            if "error" in t:
+                with pytest.raises(Exception) as ei:
+                    compat.trim_read(s, mn, mx, case["max_primer_len"], case["min_quality"], case["window"])
+                assert type(ei.value).__name__ == t["error"]
+                continue
+            flags = compat.trim_read(s, mn, mx, case["max_primer_len"], case["min_quality"], case["window"])
+            assert (s.reference_start, s.cigarstring, list(flags)) == (t["pos"], t["cigar"], t["flags"])
+            ct = exp["count_trimmed"]
+            table = [dict() for _ in range(G)]
+            if "error" in ct:
+                with pytest.raises(Exception) as ei:
+                    compat.update_base_counts(table, s, case["min_quality"])
+                assert type(ei.value).__name__ == ct["error"]
+                continue
+            compat.update_base_counts(table, s, case["min_quality"])
+            got = Counter({(p, k): n for p, d in enumerate(table) for k, n in d.items()})
+            assert got == H.sparse_from_golden(ct["counts"])
+            n_checked += 1
+    assert n_checked >= 30
+    tot, alleles = compat.alleles_from_counts({"A": 3, "C": 0, "AT": 3, "-": 1, "T": 3})
+    assert tot == 10 and [a[2] for a in alleles] == ["T", "AT", "A", "-"] and alleles[0][1] == 0.3
