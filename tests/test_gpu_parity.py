@@ -412,3 +412,29 @@ def test_function_level_seams_replay_the_named_cases():
     assert n_checked >= 30
     tot, alleles = compat.alleles_from_counts({"A": 3, "C": 0, "AT": 3, "-": 1, "T": 3})
     assert tot == 10 and [a[2] for a in alleles] == ["T", "AT", "A", "-"] and alleles[0][1] == 0.3
+
+
+@pytest.mark.parametrize("seed", list(range(3000, 3012)))
+def test_randomised_parameters_and_read_shapes(runner, seed):
+    """A slice of tools/fuzz_gpu.py: random min_quality / window / primer offset, three families of reads
+    (adversarial, indel-heavy mixed, many-op long), sorted or not; trims, counts and events equal the oracle."""
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    pr = [(s, e) for s, e, _ in primers]
+    rng = np.random.default_rng(seed)
+    mq = int(rng.choice([0, 2, 13, 20, 30, 41])); w = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 30])); off = int(rng.integers(0, 8))
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, off)
+    kind = seed % 3
+    if kind == 0:
+        segs = synth.random_segments(rng, 3000, g.size, pr)
+    elif kind == 1:
+        segs = synth.make_mixed_segments(g, amps, 3000, seed=seed)
+    else:
+        segs = _long_read_segments(rng, 800, int(g.size), int(rng.choice([300, 1200, 5000])), int(rng.choice([8, 14, 18, 22, 40, 90])))
+    if rng.random() < 0.5:
+        segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, g.size, mn, mx, mpl, mq, w)
+    assert_same(a, runner.process(b, g.size, mn, mx, mpl, mq, w), b, check_counts=False)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    assert_same(oracle.process(good, g.size, mn, mx, mpl, mq, w), runner.process(good, g.size, mn, mx, mpl, mq, w), good)
