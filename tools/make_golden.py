@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Generate tests/golden/* by running the REFERENCE's own functions in this container.
 
-Run as ``python3 -B tools/make_golden.py`` from the repo root.  The script locates
+Run as ``python3 -B tools/make_golden.py`` from the repo root (``--check``: regenerate into a scratch
+directory and compare with the committed fixtures; tests/test_golden_generator.py runs that).  The script locates
 ``/root/reference/AmpliPy.py`` at run time and refuses to run when it is absent (it is absent
-on the GPU box; only the generated fixtures travel).  ``import AmpliPy`` needs ``pysam`` only
+on the GPU box; only the generated fixtures travel) and loads it from that file, never by module
+name.  The reference's import of ``pysam`` is needed only
 for file I/O, which the hot path never touches, so an empty module object is registered under
 that name before the import.  The reference's ``trim_read`` /
 ``update_base_counts`` are then called UNMODIFIED on ``amplipy_amd.segment.Segment`` records,
@@ -18,10 +20,12 @@ below around the imported ``alleles_from_counts`` (marked ``"calls_restated": tr
 Only data is written: inputs and the reference's outputs.  No reference source is copied.
 """
 import gzip
+import importlib.util
 import json
 import os
 import shutil
 import sys
+import tempfile
 import types
 
 REF_DIR = "/root/reference"
@@ -33,10 +37,28 @@ if not os.path.isfile(os.path.join(REF_DIR, "AmpliPy.py")):
              "reference is mounted" % REF_DIR)
 
 sys.dont_write_bytecode = True
-sys.modules.setdefault("pysam", types.ModuleType("pysam"))
-sys.path.insert(0, REF_DIR)
-sys.path.insert(0, ROOT)
-import AmpliPy as REF  # noqa: E402  (the reference, imported by path)
+
+
+def load_reference():
+    """The reference module, loaded from its FILE -- never by module name: the repo root holds an
+    `AmpliPy.py` of its own (the drop-in entry point), and fixtures pinned to that would pin the oracle
+    to the product.  The origin is asserted."""
+    sys.modules.setdefault("pysam", types.ModuleType("pysam"))
+    path = os.path.join(REF_DIR, "AmpliPy.py")
+    spec = importlib.util.spec_from_file_location("amplipy_reference", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    origin = os.path.realpath(mod.__file__)
+    assert origin.startswith(os.path.realpath(REF_DIR) + os.sep), "reference loaded from %s" % origin
+    for name in ("find_overlapping_primers", "get_pos_on_query", "get_pos_on_ref", "fix_cigar", "trim_read",
+                 "update_base_counts", "alleles_from_counts", "load_primers", "load_ref_genome", "VERSION"):
+        assert hasattr(mod, name), "reference module lacks %s" % name
+    return mod
+
+
+REF = load_reference()
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 from amplipy_amd.segment import Segment, format_cigar, parse_cigar  # noqa: E402
@@ -366,5 +388,40 @@ def main():
          gz=True)
 
 
+def check():
+    """Regenerate everything into a scratch directory and compare with tests/golden byte for byte
+    (.npz members array for array: the zip container carries timestamps)."""
+    global OUT
+    committed = OUT
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        try:
+            main()
+        finally:
+            OUT = committed
+        names = sorted(f for f in os.listdir(tmp) if os.path.isfile(os.path.join(tmp, f)))
+        names += sorted(os.path.join("data", f) for f in os.listdir(os.path.join(tmp, "data")))
+        for fn in names:
+            a, b = os.path.join(tmp, fn), os.path.join(committed, fn)
+            if not os.path.isfile(b):
+                bad.append(fn + " (not committed)")
+            elif fn.endswith(".npz"):
+                za, zb = np.load(a), np.load(b)
+                if sorted(za.files) != sorted(zb.files) or any(not np.array_equal(za[k], zb[k]) for k in za.files):
+                    bad.append(fn)
+            elif open(a, "rb").read() != open(b, "rb").read():
+                bad.append(fn)
+        extra = sorted(set(f for f in os.listdir(committed) if os.path.isfile(os.path.join(committed, f))) - set(names))
+        bad += [fn + " (committed, not generated)" for fn in extra]
+    if bad:
+        sys.exit("make_golden --check: DIFFERENT from tests/golden: " + ", ".join(bad))
+    print("make_golden --check: %d files identical to tests/golden (reference %s from %s)"
+          % (len(names), REF.VERSION, REF.__file__))
+
+
 if __name__ == "__main__":
-    main()
+    if "--check" in sys.argv[1:]:
+        check()
+    else:
+        main()
