@@ -54,9 +54,6 @@ struct EventBuf {
     // One cursor per shard (block id modulo EV_SHARDS): a single hot counter serialises the chip.
     __device__ void record(int32_t pos, uint32_t read, int32_t lo, int32_t hi) const {
         const unsigned s = blockIdx.x & (EV_SHARDS - 1);
-#ifdef AMP_EXP_NO_EVENTS
-        return;
-#endif
         unsigned long long idx = atomicAdd(&ctr[16 + s], 1ull);
         if ((long long)idx < cap) ev[(size_t)s * (size_t)cap + idx] = amp_ins_event{pos, read, lo, hi};
         atomicAdd(&ins_at[pos], 1u);
@@ -390,15 +387,11 @@ AMP_HD bool is_simple_cigar(int n, uint32_t w0, int32_t lseq) {
     return n == 1 && (op == OP_M || op == OP_EQ || op == OP_X) && lseq > 0 && (int32_t)(w0 >> 4) == lseq;
 }
 
-// trim_primers for a simple read; `sc` starts as {op, 0, l_seq, 0}
-AMP_HD void trim_primers_simple(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, SimpleCig &sc) {
+// trim_primers for a simple read given the two table entries of A:450-451; `sc` starts as {op, 0, l_seq, 0}
+AMP_HD void trim_primers_simple_tab(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, SimpleCig &sc,
+                                    int32_t left_max_end, int32_t right_min_start) {
     const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
     const int32_t rs = st.pos, L = lseq;
-    if ((uint32_t)rs >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }       // A:450
-    const int32_t re1 = rs + L - 1;
-    if ((uint32_t)re1 >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }      // A:451
-    const int32_t left_max_end = P.max_end[rs];
-    const int32_t right_min_start = P.min_start[re1];
     const int32_t at = tlen < 0 ? -tlen : tlen;
     const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;              // A:452
     if (!(is_paired && isize_flag && is_reverse) && left_max_end >= 0) {                   // A:460
@@ -423,6 +416,15 @@ AMP_HD void trim_primers_simple(const KParams &P, TrimState &st, uint32_t flag, 
             }
         }
     }
+}
+
+// trim_primers for a simple read
+AMP_HD void trim_primers_simple(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, SimpleCig &sc) {
+    const int32_t rs = st.pos;
+    if ((uint32_t)rs >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }       // A:450
+    const int32_t re1 = rs + lseq - 1;
+    if ((uint32_t)re1 >= (uint32_t)P.ref_len) { st.err = AMP_RS_INDEX_REF; return; }      // A:451
+    trim_primers_simple_tab(P, st, flag, tlen, lseq, sc, P.max_end[rs], P.min_start[re1]);
 }
 
 // trim_quality_apply for a simple read (the window of quality_window is lo = a, qlen = m)

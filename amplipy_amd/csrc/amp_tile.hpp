@@ -55,6 +55,16 @@ constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;   // counted by the tile ker
 constexpr uint32_t DEFER_INDELS = 0x40000000u;        // match bases counted by the tile kernel; deletions / insertion events missing
 constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 
+// The general pass of variant 4 (amp_fast.hpp) runs this kernel over a LIST of reads: entries are read index | kind
+constexpr uint32_t GL_STATUS_ONLY = 0x80000000u;   // counted by the fast kernel; a base could not be counted: exact status wanted
+constexpr uint32_t GL_INDEX_MASK = 0x3FFFFFFFu;
+struct GenGeo {            // geometry of the general pass, decided on the device by k_gcompact
+    uint32_t n_list;       // entries of the dense list
+    uint32_t tpb;          // tiles per block of k_tile<LIST>
+    uint32_t n_seg;        // its blocks that have tiles
+    uint32_t pad;
+};
+
 // per-read state words kept in LDS for the chunk lanes
 enum : int { S_OFF8, S_LOHI, S_FF, S_REV, S_ERR, S_CB2, S_WORDS };
 enum : int { G_M, G_R0, G_RC, G_WORDS };   // per-segment words; G_RC = owner lane | chunk base << 8 (the read's offset is st[S_OFF8][lane])
@@ -493,18 +503,33 @@ struct SplitDesc {
 };
 constexpr uint32_t SD_DEFER = 1u << 24, SD_HAVE_QUAL = 1u << 25, SD_CAN_Q = 1u << 26, SD_REV = 1u << 27;
 
-template <bool STAMPS, bool SPLIT>
+// LIST: the tile's reads are entries [tile * 64, tile * 64 + 64) of `rlist` (ascending read order inside each
+// fast-kernel block's share), the number of entries and the tiles per block come from `geo` (device memory).
+// dcnt_stride = blocks the list counts were sized for (the grid; LIST: the host's worst-case grid).
+#ifdef AMP_DEV
+#define AMP_PHASES_PARAM , uint32_t phases
+#define AMP_PHASES_ARG(x) , (x)
+#else
+#define AMP_PHASES_PARAM
+#define AMP_PHASES_ARG(x)
+#endif
+template <bool STAMPS, bool SPLIT, bool LIST>
 __global__ void __launch_bounds__(T_WAVES * 64, 4)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
-       uint32_t *dcnt, int tiles_per_block, uint32_t phases, SplitDesc sd) {
+       uint32_t *dcnt, int tiles_per_block, SplitDesc sd, const uint32_t *rlist, const GenGeo *geo,
+       uint32_t dcnt_stride AMP_PHASES_PARAM) {
+#ifndef AMP_DEV
+    constexpr uint32_t phases = 0xFFu;     // the shipped library cannot mask phases off
+#endif
     __shared__ BlockLds L;
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t n = rd.n_reads;
+    if (LIST) tiles_per_block = (int)geo->tpb;
+    const int64_t n = LIST ? (int64_t)geo->n_list : rd.n_reads;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_block;
     const int64_t tile_end = tile_begin + tiles_per_block < n_tiles ? tile_begin + tiles_per_block : n_tiles;
-    if (tile_begin >= tile_end) { if (threadIdx.x == 0) dcnt[blockIdx.x] = 0; return; }
+    if (tile_begin >= tile_end) { if (threadIdx.x == 0) { dcnt[blockIdx.x] = 0; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = 0; } return; }
 
     lds_u32 *const win = (lds_u32 *)L.win;
     lds_u32 *const lut = (lds_u32 *)L.lut;
@@ -529,7 +554,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
         // ---- window management (uniform over the block) ------------------------------------
-        const int32_t first_pos = rd.pos[t0 * TILE];
+        const int32_t first_pos = rd.pos[LIST ? (int64_t)(rlist[t0 * TILE] & GL_INDEX_MASK) : t0 * TILE];
         if (win_base == NO_WINDOW || first_pos < win_base || first_pos - win_base >= T_W / 2) {
             __syncthreads();
             if (win_base != NO_WINDOW) {
@@ -558,8 +583,12 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 #define AMP_STAMP(k) do { if (stamps) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } } while (0)
         // =================================== P1: lane = read ===================================
-        const int64_t i = tile * TILE + lane;
-        const bool valid = i < n;
+        const int64_t li = tile * TILE + lane;           // row of the batch, or of the list
+        const bool valid = li < n;
+        uint32_t lent = 0;
+        if (LIST && valid) lent = rlist[li];
+        const int64_t i = LIST ? (int64_t)(lent & GL_INDEX_MASK) : li;
+        const bool status_wanted = LIST && (lent & GL_STATUS_ONLY);      // the fast kernel counted it: exact status only
         int32_t lseq = 0, pos = 0, tlen = 0;
         uint32_t flag = 0, c0 = 0, off8 = 0, meta = 0, lohi = 0;
         int ncig = 0;
@@ -571,7 +600,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const size_t slot = (size_t)c0 + 3 * (size_t)(valid ? i : 0);
         const int64_t boff = (int64_t)off8 * 8;
         const uint8_t *qual = rd.qual + boff;
-        bool defer_full = SPLIT ? (meta & SD_DEFER) != 0 : valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u);
+        bool defer_full = SPLIT ? (meta & SD_DEFER) != 0 : valid && (ncig + 3 > T_MAXOPS || (uint32_t)lseq >= 65536u || status_wanted);
         LdsCig cur{cigA + lane}, tmp{cigB + lane};
         uint32_t q0 = 0xFFu;
         if (!SPLIT) {
@@ -778,13 +807,14 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             uint32_t entry = 0;
             bool has = false;
             if (valid) {
-                if (defer_full) { entry = (uint32_t)i; has = true; status = 0; }
+                if (status_wanted) { entry = (uint32_t)i | DEFER_STATUS_ONLY; has = true; status = 0; }
+                else if (defer_full) { entry = (uint32_t)i; has = true; status = 0; }
                 else if (!status && P.do_count) {
                     if (defer_indels) { entry = (uint32_t)i | DEFER_INDELS; has = true; }
                     if (st[S_ERR * TILE + lane]) { entry |= (uint32_t)i | DEFER_STATUS_ONLY; has = true; }
                 }
                 if (status) ++n_err;
-                if (out.status) out.status[i] = (uint8_t)status;
+                if (out.status && !status_wanted) out.status[i] = (uint8_t)status;
             }
             // A single hot counter in global memory would serialise the whole chip (one returning atomic
             // per tile); every block appends to its OWN segment of the list through an LDS counter.
@@ -825,7 +855,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
     if (tid == 0) {
-        dcnt[blockIdx.x] = L.dcount; dcnt[5 * gridDim.x + 64 + blockIdx.x] = L.dcount2;
+        dcnt[blockIdx.x] = L.dcount; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = L.dcount2;
         // (no per-block atomic on a shared counter here: thousands of blocks on one address serialise;
         //  amp_debug_counters sums the per-block list counts instead)
     }
@@ -839,9 +869,9 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             atomicMax(&ctr[14], (dur << 16) | (unsigned long long)(blockIdx.x & 0xFFFF));            // slowest block and its id
             atomicMax(&ctr[5], ((0xFFFFFFFFFFFFull - dur) << 16) | (unsigned long long)(blockIdx.x & 0xFFFF));   // fastest block
             atomicAdd(&ctr[4], dur);
-            dcnt[gridDim.x + 64 + blockIdx.x * 4 + 0] = (uint32_t)dur; dcnt[gridDim.x + 64 + blockIdx.x * 4 + 1] = bs_rebase;
+            dcnt[dcnt_stride + 64 + blockIdx.x * 4 + 0] = (uint32_t)dur; dcnt[dcnt_stride + 64 + blockIdx.x * 4 + 1] = bs_rebase;
         }
-        if (lane == 0) { atomicAdd(&dcnt[gridDim.x + 64 + blockIdx.x * 4 + 2], bs_c2); atomicAdd(&dcnt[gridDim.x + 64 + blockIdx.x * 4 + 3], bs_c4); }
+        if (lane == 0) { atomicAdd(&dcnt[dcnt_stride + 64 + blockIdx.x * 4 + 2], bs_c2); atomicAdd(&dcnt[dcnt_stride + 64 + blockIdx.x * 4 + 3], bs_c4); }
     }
 }
 
@@ -864,8 +894,11 @@ static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_
     if (rd.n_reads == 0) return 0;
     const TileGrid tg = tile_grid(rd.n_reads, n_cu);
     const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
-    if (phases & 0x100u) k_tile<true, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, none);
-    else k_tile<false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, none);
+#ifdef AMP_DEV
+    if (phases & 0x100u) k_tile<true, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
+    else
+#endif
+    k_tile<false, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
     return (int)hipGetLastError();
 }
 
@@ -968,7 +1001,7 @@ static inline int split_launch(const KParams &P, const amp_dev_reads &rd, uint64
     const unsigned g1 = (unsigned)((rd.n_reads + S_WAVES * 64 - 1) / (S_WAVES * 64));
     k_trim<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, out, sd);
     if (P.do_trim && P.window <= 8 && (phases & 2u)) k_scan<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, sd, phases);
-    k_tile<false, true><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, phases, sd);
+    k_tile<false, true, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, sd, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
     return (int)hipGetLastError();
 }
 

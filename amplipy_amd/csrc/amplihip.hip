@@ -18,6 +18,7 @@
 #include "../../include/amplihip.h"
 #include "amp_read.hpp"
 #include "amp_tile.hpp"
+#include "amp_fast.hpp"
 
 using namespace amp;
 
@@ -75,9 +76,10 @@ struct amp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timed = false;
     int n_cu = 256;
-    int kernel_variant = 2;       // 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>
+    int kernel_variant = 4;       // 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
+                                  // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
-    uint32_t phases = 0xFFu;       // debug: phases of the tile kernel to run (AMPLIHIP_PHASES)
+    uint32_t phases = 0xFFu;       // always 0xFF in the shipped library; -DAMP_DEV builds can mask phases of the tile kernel (AMPLIHIP_PHASES)
     char err[320] = {0};
 };
 
@@ -450,7 +452,9 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
 // have deletions / insertion events left; one per lane off the front of the block's list segment.
 __global__ void __launch_bounds__(256)
 k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg,
+                 const GenGeo *geo, long long dcnt_stride) {
+    if (geo) { tiles_per_block = (long long)geo->tpb; n_seg = (long long)geo->n_seg; }   // general pass of variant 4
     __shared__ uint32_t s_cig[T_MAXOPS * 256];
     __shared__ uint32_t s_ev[4 * D_EVCAP];
     __shared__ uint32_t s_nev;
@@ -468,7 +472,7 @@ k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
     }
     if (threadIdx.x == 0) {      // tell the heavy pass whether it has anything to do at all (ctr[24], sticky until amp_reset)
         uint32_t hv = 0;
-        for (int w = 0; w < D_LSEG; ++w) { const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w; if (s2 < n_seg) hv |= dcnt[5 * n_seg + 64 + s2]; }
+        for (int w = 0; w < D_LSEG; ++w) { const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w; if (s2 < n_seg) hv |= dcnt[5 * dcnt_stride + 64 + s2]; }
         if (hv) atomicOr(&eb.ctr[24], 1ull);
     }
     if (cmax == 0) return;
@@ -509,7 +513,8 @@ struct HeavyLds {
 template <bool SPARSE>
 __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
                                            uint32_t *scratch, uint32_t *counts, const EventBuf &eb, const uint32_t *dlist,
-                                           const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
+                                           const uint32_t *dcnt, long long tiles_per_block, long long n_seg, long long dcnt_stride,
+                                           const uint32_t *rlist) {
     uint32_t *const s_cig = L.cig, *const s_win = L.win, *const s_coop = L.coop, *const s_ev = L.ev, *const s_ucnt = L.ucnt;
     uint32_t &s_ncoop = L.ncoop, &s_nev = L.nev;
     unsigned long long &s_evbase = L.evbase, &s_mask = L.mask;
@@ -523,8 +528,8 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
         uint32_t tot = 0, own = 0;
         if (it < n_item) {
             const int64_t unit = SPARSE ? it : it / D_UNIT;
-            for (int j = 0; j < D_UNIT; ++j) { const int64_t sbj = unit * D_UNIT + j; if (sbj < n_seg) tot += dcnt[5 * n_seg + 64 + sbj]; }
-            own = SPARSE ? tot : dcnt[5 * n_seg + 64 + it];
+            for (int j = 0; j < D_UNIT; ++j) { const int64_t sbj = unit * D_UNIT + j; if (sbj < n_seg) tot += dcnt[5 * dcnt_stride + 64 + sbj]; }
+            own = SPARSE ? tot : dcnt[5 * dcnt_stride + 64 + it];
         }
         const unsigned long long mk = __ballot(own != 0 && (tot <= 256u) == SPARSE);
         if (threadIdx.x == 0) s_mask = mk;
@@ -543,14 +548,15 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
         for (int j = 0; j < D_UNIT; ++j) {
             s_ucnt[j] = acc;
             const int64_t sbj = sb_first + j;
-            if (sbj < n_seg && (SPARSE || j == 0)) acc += dcnt[5 * n_seg + 64 + sbj];
+            if (sbj < n_seg && (SPARSE || j == 0)) acc += dcnt[5 * dcnt_stride + 64 + sbj];
         }
         s_ucnt[D_UNIT] = acc;
         s_ncoop = 0; s_nev = 0;
     }
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
     // sorted input: no read of this pass starts left of the first read of its first tile range
-    int32_t base = rd.pos[sb_first * tiles_per_block * TILE];
+    const int64_t first_row = sb_first * tiles_per_block * TILE;
+    int32_t base = rd.pos[rlist ? (int64_t)(rlist[first_row] & GL_INDEX_MASK) : first_row];
     if (base < 0) base = 0;
     __syncthreads();
     const uint32_t cnt = s_ucnt[D_UNIT];
@@ -643,12 +649,14 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
 // kernel holds the LDS of every CU
 __global__ void __launch_bounds__(256)
 k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg) {
+                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg,
+                 const GenGeo *geo, long long dcnt_stride, const uint32_t *rlist) {
     __shared__ HeavyLds L;
     if (__hip_atomic_load(&eb.ctr[24], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // set by k_deferred_light
-    heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg);
+    if (geo) { tiles_per_block = (long long)geo->tpb; n_seg = (long long)geo->n_seg; }
+    heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
     __syncthreads();
-    heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg);
+    heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
 }
 
 __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
@@ -880,10 +888,12 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
+#ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
-    if (v && v[0] >= '1' && v[0] <= '3') c->kernel_variant = v[0] - '0';
+    if (v && v[0] >= '1' && v[0] <= '4') c->kernel_variant = v[0] - '0';
     v = getenv("AMPLIHIP_PHASES");
     if (v) c->phases = (uint32_t)strtoul(v, nullptr, 0);
+#endif
     *out = c;
     return AMP_OK;
 }
@@ -950,8 +960,8 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
     return AMP_OK;
 }
 
-int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline
-    if (!c || variant < 1 || variant > 3) return AMP_EINVAL;
+int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 = fast + general pass
+    if (!c || variant < 1 || variant > 4) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -995,42 +1005,70 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const size_t slots = (size_t)rd->n_cig + 3 * (size_t)n;
     DevOut out{o ? o->new_pos : nullptr, o ? o->new_ncig : nullptr, o ? o->new_cig : nullptr, o ? o->ref_len : nullptr,
                o ? o->trim_flags : nullptr, o ? o->status : nullptr};
-    // scratch: [CIGAR ping-pong slots][deferred list][outputs the caller did not ask for but the second pass reads]
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
+    // windows wider than a chunk take the serial scan of the general kernel: no fast pass for them
+    const int variant = (c->kernel_variant == 4 && c->window > 8) ? 2 : c->kernel_variant;
     const TileGrid tg = tile_grid(n, c->n_cu);
-    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + (size_t)tg.grid * (size_t)tg.tpb * TILE) * 4));
+    const FastGrid fg = fast_grid(n);
+    // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
+    // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
+    const size_t dlist_words = ((size_t)tg.grid + 1) * (size_t)tg.tpb * TILE;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid + (size_t)n + 64 : 0;
+    HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
-    uint32_t *dcnt = dlist + (size_t)tg.grid * (size_t)tg.tpb * TILE;  // entries used in each segment
+    uint32_t *dcnt = dlist + dlist_words;                             // entries used in each segment
     uint32_t *extra = dcnt + tg.grid * 6 + 64;           // [grid] light counts | 64 | [4*grid] debug | [grid] heavy counts
     SplitDesc sd{(int32_t *)extra, extra + n, extra + 2 * n, extra + 3 * n};      // variant 3 hand-over arrays
     extra += 4 * n;
     c->dbg_dcnt = dcnt; c->dbg_grid = (int)tg.grid;
+#ifdef AMP_DEV
     if (c->phases & 0x100u) HIPCHK(c, hipMemsetAsync(dcnt, 0, ((size_t)tg.grid * 5 + 64) * 4, c->stream));
+#endif
     if (!out.new_pos) { out.new_pos = (int32_t *)extra; }
     extra += n;
     if (!out.new_ncig) { out.new_ncig = extra; }
     extra += n;
-    if (!out.new_cig) out.new_cig = extra;
+    if (!out.new_cig) { out.new_cig = extra; extra += slots; }
+    uint32_t *glist = extra, *gcnt = glist + (size_t)fg.grid * (size_t)fg.rpb, *gdense = gcnt + fg.grid;
+    GenGeo *geo = (GenGeo *)(gdense + ((n + 3) & ~(int64_t)3));
     const EventBuf eb{c->events.as<amp_ins_event>(), c->d_ctr, c->d_ins_at, (long long)c->ev_cap};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->kernel_variant == 1) {
+    if (variant == 1) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         k_reads_lane<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+    } else if (variant == 4) {
+        // fast pass over the simple reads, then the general tile kernel over the list of the others
+        const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        k_fast<<<(unsigned)fg.grid, F_WAVES * 64, 0, c->stream>>>(P, *rd, out, c->d_counts, c->d_ctr, glist, gcnt, (int)fg.rpb);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, gdense, geo, (uint32_t)tg.grid);
+        HIPCHK(c, hipGetLastError());
+        k_tile<false, false, true><<<(unsigned)tg.grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
+                                                                                    gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
+        HIPCHK(c, hipGetLastError());
+        k_deferred_light<<<(unsigned)((tg.grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo,
+                                                                               (long long)tg.grid);
+        HIPCHK(c, hipGetLastError());
+        k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
+            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo, (long long)tg.grid, gdense);
+        HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int rc = c->kernel_variant == 3
+        int rc = variant == 3
                      ? split_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, sd, c->stream)
                      : tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         k_deferred_light<<<(unsigned)((tg.grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
-                                                                               (long long)tg.tpb, (long long)tg.grid);
+                                                                               (long long)tg.tpb, (long long)tg.grid, nullptr, (long long)tg.grid);
         HIPCHK(c, hipGetLastError());
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
-            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, (long long)tg.tpb, (long long)tg.grid);
+            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, (long long)tg.tpb, (long long)tg.grid, nullptr, (long long)tg.grid, nullptr);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));

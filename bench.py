@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--depth", type=int, default=10000, help="mean coverage per GPU (10000 -> 1,993,533 reads)")
     ap.add_argument("--cpu-passes", type=int, default=12, help="passes of the CPU baseline over the batch (0 = skip)")
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=4)
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()

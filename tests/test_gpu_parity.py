@@ -12,7 +12,7 @@ from tests.gpu_util import GpuRunner, assert_same
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 2, 3], ids=["lane_kernel", "tile_kernel", "split_pipeline"])
+@pytest.fixture(scope="module", params=[4, 2, 1, 3], ids=["fast_kernel", "tile_kernel", "lane_kernel", "split_pipeline"])
 def runner(request):
     r = GpuRunner(variant=request.param)
     yield r
@@ -130,7 +130,7 @@ def test_replication_property_full_depth(runner, scheme):
     a = oracle.process(base, g.size, mn, mx, mpl)
     e = runner.engine(g.size)
     e.reset(); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
-    k = 100 if runner.variant == 2 else 10
+    k = 100 if runner.variant == 4 else 10
     for rep in range(k):
         e.process(base, read_base=0, want_trim=False)
     assert np.array_equal(e.counts(), a.counts * np.uint32(k))
@@ -218,7 +218,7 @@ def test_device_double_division_is_python_division(runner):
 @pytest.mark.parametrize("ext", ["sam", "bam"])
 def test_end_to_end_aio_cli(tmp_path, ext, runner, monkeypatch):
     """run_amplipy 'aio' on files: trimmed reads, VCF and consensus agree with the golden pileup."""
-    if runner.variant != 2:
+    if runner.variant != 4:
         pytest.skip("the CLI always uses the default kernel")
     from amplipy_amd import amplipy, bamio
     g = H.load_json("pileup_5000.json.gz")
