@@ -8,8 +8,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "amplihip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "amp_read.hpp"), os.path.join(_HERE, "csrc", "amp_tile.hpp"),
-        os.path.join(_HERE, "..", "include", "amplihip.h")]
+DEPS = [SRC, os.path.join(_HERE, "..", "include", "amplihip.h")] + sorted(
+    os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".hpp"))
 OUT = os.path.join(_HERE, "libamplihip.so")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 

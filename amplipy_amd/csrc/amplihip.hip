@@ -1006,10 +1006,11 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     DevOut out{o ? o->new_pos : nullptr, o ? o->new_ncig : nullptr, o ? o->new_cig : nullptr, o ? o->ref_len : nullptr,
                o ? o->trim_flags : nullptr, o ? o->status : nullptr};
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
-    // windows wider than a chunk take the serial scan of the general kernel: no fast pass for them
-    const int variant = (c->kernel_variant == 4 && c->window > 8) ? 2 : c->kernel_variant;
+    // windows wider than a chunk take the serial scan of the general kernel, and the fast kernel's byte-parallel
+    // quality test is written for min_quality <= 128: no fast pass for such runs
+    const int variant = (c->kernel_variant == 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : c->kernel_variant;
     const TileGrid tg = tile_grid(n, c->n_cu);
-    const FastGrid fg = fast_grid(n);
+    const FastGrid fg = fast_grid(n, c->n_cu);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     const size_t dlist_words = ((size_t)tg.grid + 1) * (size_t)tg.tpb * TILE;
@@ -1043,8 +1044,9 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        k_fast<<<(unsigned)fg.grid, F_WAVES * 64, 0, c->stream>>>(P, *rd, out, c->d_counts, c->d_ctr, glist, gcnt, (int)fg.rpb);
-        HIPCHK(c, hipGetLastError());
+        if (fast_launch(P, *rd, out, c->d_counts, c->d_ctr, glist, gcnt, fg, c->stream) != 0) {
+            snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
+        }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, gdense, geo, (uint32_t)tg.grid);
         HIPCHK(c, hipGetLastError());
