@@ -32,9 +32,11 @@
 
 namespace amp {
 
-constexpr int F_WAVES = 8;            // waves per block
+constexpr int F_WAVES = 8;            // waves per block (one block per CU: LDS)
 constexpr int F_NP = 10;              // 16-base pieces per read held in registers: reads of up to 160 bases
 constexpr int F_W = 512;              // reference positions covered by the block's LDS window
+constexpr int F_NPL = 4;              // count planes kept in LDS: A C G T (N and '-' never take the fast path)
+constexpr int F_STAGE = 10240;        // bytes of a wave's staging buffer = the longest run of quality bytes a tile may span
 #ifndef AMP_F_REP
 #define AMP_F_REP 4
 #endif
@@ -43,17 +45,18 @@ constexpr int F_W = 512;              // reference positions covered by the bloc
 #endif
 constexpr int F_REP = AMP_F_REP;              // replicas of the window (lanes that hold the same piece use different ones)
 constexpr int F_PLANE = F_W * 4;      // bytes per symbol plane
-constexpr int F_REPW = AMP_NSYM * F_W + AMP_F_SKEW;   // words per replica: one word of skew, so that replica r is shifted by r banks
+constexpr int F_REPW = F_NPL * F_W + AMP_F_SKEW;   // words per replica: one word of skew, so that replica r is shifted by r banks
 
 struct FastLds {
+    uint4 stage[F_WAVES][F_STAGE / 16 + 2];   // per wave: the tile's quality bytes, then its packed bases (coalesced loads in, rows out)
     uint32_t win[F_REP * F_REPW];
     uint32_t gcount;                  // entries of this block's segment of the general list
 };
 
 struct FastGrid { int64_t grid, rpb; };
 static inline FastGrid fast_grid(int64_t n_reads, int n_cu) {
-    // eight blocks per CU (two are resident); a wave gets at least two tiles of 64 reads
-    int64_t rpb = (n_reads + 8 * (int64_t)n_cu - 1) / (8 * (int64_t)n_cu);
+    // four blocks per CU (one is resident); a wave gets at least two tiles of 64 reads
+    int64_t rpb = (n_reads + 4 * (int64_t)n_cu - 1) / (4 * (int64_t)n_cu);
     rpb = ((rpb + F_WAVES * 64 - 1) / (F_WAVES * 64)) * (F_WAVES * 64);
     if (rpb < 2 * F_WAVES * 64) rpb = 2 * F_WAVES * 64;
     return FastGrid{(n_reads + rpb - 1) / rpb, rpb};
@@ -100,8 +103,21 @@ __device__ __forceinline__ uint32_t piece_fail_bits(const uint4 &q, const uint2 
            (window_fail_bits16<W>(make_uint2(q.z, q.w), nx, thr) << 8);
 }
 
+// in-kernel phase stamps (development builds only; the numbers are shares, not durations)
+#ifdef AMP_DEV
+#define F_STAMP_DECL unsigned long long f_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_prev = __builtin_amdgcn_s_memtime()
+#define F_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define F_STAMP_VM(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0070); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define F_STAMP_OUT do { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f_t[k]); } while (0)
+#else
+#define F_STAMP_DECL
+#define F_STAMP(k)
+#define F_STAMP_VM(k)
+#define F_STAMP_OUT
+#endif
+
 template <int W>
-__global__ void __launch_bounds__(F_WAVES * 64, 4)
+__global__ void __launch_bounds__(F_WAVES * 64, 2)
 k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long long *ctr, uint32_t *glist, uint32_t *gcnt,
        int reads_per_block) {
     __shared__ FastLds L;
@@ -112,9 +128,10 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
     lds_u32 *const win = (lds_u32 *)L.win;
     for (int i = tid; i < F_REP * F_REPW; i += F_WAVES * 64) win[i] = 0;
     if (tid == 0) L.gcount = 0;
-    // the block's window: anchored at its first read (sorted input: nothing of this block starts left of it)
+    // the block's window: anchored 16 positions left of its first read (sorted input: nothing of this block starts
+    // left of that read; the margin keeps the piece that straddles a read's first counted base inside the window)
     int32_t win_base = rb < n ? rd.pos[rb] : 0;
-    win_base = (win_base < 0 ? 0 : win_base) & ~31;
+    win_base = (win_base < 16 ? 0 : win_base - 16) & ~15;
     uint32_t wlim;
     {
         const int64_t lim = (int64_t)P.ref_len - win_base;
@@ -145,43 +162,177 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
 #pragma unroll
     for (int g = 0; g < 4; ++g) gdelta[g] = 0 * (int32_t)rotb;   // TEMP: rotation needs the data rotated too
 
-    for (int64_t i0 = wbeg; i0 < wend; i0 += 64) {
-        const int64_t i = i0 + lane;
-        const bool valid = i < wend;
-        int32_t pos = 0, tlen = 0;
-        uint32_t lseq = 0, flag = 0, c0 = 0, c1 = 0, o8 = 0;
-        if (valid) {
-            pos = rd.pos[i]; flag = rd.flag[i]; tlen = rd.tlen[i]; lseq = rd.lseq[i];
-            c0 = rd.cig_off32[i]; c1 = rd.cig_off32[i + 1]; o8 = rd.seq_off8[i];
+    lds_u8 *const stage = (lds_u8 *)L.stage[wave];
+    F_STAMP_DECL;
+
+    // ---- software pipeline: while tile t is computed from registers, the bytes of tile t + 1 are on their way --
+    // (qualities by LDS-DMA straight into the wave's staging buffer, which is idle once the rows of tile t are
+    // in registers; packed bases, first CIGAR word and primer-table entries into registers; the header of
+    // tile t + 2 into registers)
+    struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };
+    struct Geo { uint32_t np, row, Tq; int ntake; bool solo, taken, shortq, fastq, in_ref; };
+    struct L2 { uint32_t w0; int32_t tabL, tabR; uint2 raws[F_STAGE / 1024];
+#ifdef AMP_F_NODMA
+        uint2 rawq[F_STAGE / 512];
+#endif
+    };
+    auto load_hdr = [&](int64_t t0) {
+        Hdr h{0, 0, 0u, 0u, 0u, 0u, 0u};
+        const int64_t i = t0 + lane;
+        if (i < wend) {
+            h.pos = rd.pos[i]; h.flag = rd.flag[i]; h.tlen = rd.tlen[i]; h.lseq = rd.lseq[i];
+            h.c0 = rd.cig_off32[i]; h.c1 = rd.cig_off32[i + 1]; h.o8 = rd.seq_off8[i];
         }
-        // ---- second level of loads, all issued before any is waited for ------------------------------------
-        // first what the trims need (first CIGAR word; the two primer-table entries of A:450-451, which for a
-        // simple read depend on the header only), then the read's bytes: vmcnt retires in order, so the wait for
-        // the former leaves the latter in flight
-        const bool shortq = valid && lseq >= 1u && lseq <= (uint32_t)(F_NP * 16);
-        uint32_t w0 = 0;
-        if (shortq && c1 > c0) w0 = rd.cig[c0];
-        const bool in_ref = (uint32_t)pos < G && (uint32_t)(pos + (int32_t)lseq - 1) < G;        // A:450-451
-        int32_t tabL = -1, tabR = -1;
-        if (shortq && P.do_trim && in_ref) { tabL = P.max_end[pos]; tabR = P.min_start[pos + (int32_t)lseq - 1]; }
-        // pieces: np of them; slot k holds piece (k + rot) mod np (slots >= np hold a copy of the last piece and
-        // get an index past the read, which every range test below excludes)
-        const uint32_t np = shortq ? (lseq + 15u) >> 4 : 1u;
+        return h;
+    };
+    // the tile: the leading reads whose bytes form one run of at most F_STAGE quality bytes
+    auto geometry = [&](const Hdr &h, int64_t t0, uint32_t &m0) {
+        Geo g;
+        const bool valid = t0 + lane < wend;
+        g.shortq = valid && h.lseq >= 1u && h.lseq <= (uint32_t)(F_NP * 16);
+        g.np = g.shortq ? (h.lseq + 15u) >> 4 : 1u;
+        m0 = __builtin_amdgcn_readfirstlane(h.o8);
+        g.row = (h.o8 - m0) * 8u;                                            // byte offset of the read's qualities in the run
+        const uint32_t nch = (h.lseq + 7u) >> 3;
+        // a row is read as np pieces of 16 bytes: up to 8 bytes past the read's own padded bytes
+        const bool fits = valid && h.o8 >= m0 && (h.o8 - m0) <= (uint32_t)(F_STAGE / 8) && g.row + 16u * g.np <= (uint32_t)F_STAGE + 8u &&
+                          (g.shortq || g.row + 8u * nch <= (uint32_t)F_STAGE);
+        const unsigned long long fitmask = __ballot(fits);
+        g.ntake = fitmask == ~0ull ? 64 : __builtin_ctzll(~fitmask);
+        g.solo = g.ntake == 0;                                                // the first read alone is too long: general pass
+        if (g.solo) g.ntake = 1;
+        g.taken = lane < g.ntake && !g.solo;
+        g.Tq = g.solo ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)(g.row + 8u * nch), g.ntake - 1);   // bytes of the run (scalar)
+        g.Tq = g.Tq > (uint32_t)F_STAGE ? (uint32_t)F_STAGE : g.Tq;
+        g.fastq = g.taken && g.shortq;
+        g.in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + (int32_t)h.lseq - 1) < G;          // A:450-451
+        return g;
+    };
+    // second level of loads: first CIGAR word, the two primer-table entries of A:450-451 (for a simple read they
+    // depend on the header only), the tile's quality bytes by LDS-DMA (lane l moves bytes [1024 s + 16 l, + 16) of
+    // the run to the same offset of the staging buffer) and its packed bases (8 bytes per lane and load)
+    auto issue_l2 = [&](const Hdr &h, const Geo &g, uint32_t m0) {
+        L2 x;
+        x.w0 = 0; x.tabL = -1; x.tabR = -1;
+        if (g.fastq && h.c1 > h.c0) x.w0 = rd.cig[h.c0];
+        if (g.fastq && P.do_trim && g.in_ref) { x.tabL = P.max_end[h.pos]; x.tabR = P.min_start[h.pos + (int32_t)h.lseq - 1]; }
+        const uint8_t *qrun = rd.qual + (int64_t)m0 * 8;
+        const uint8_t *srun = rd.seq + (int64_t)m0 * 4;
+        // lanes past the run re-read its end
+        const uint32_t lastq = g.Tq ? (g.Tq - 1u) & ~15u : 0u, lasts = g.Tq ? ((g.Tq >> 1) - 1u) & ~7u : 0u;
+#ifdef AMP_F_NODMA
+        const uint32_t lastq8 = g.Tq ? (g.Tq - 1u) & ~7u : 0u;
+#pragma unroll
+        for (int sl = 0; sl < F_STAGE / 512; ++sl) {
+            uint32_t off = (uint32_t)(sl * 512 + lane * 8);
+            off = off < lastq8 ? off : lastq8;
+            x.rawq[sl] = *(const uint2 *)(qrun + off);
+        }
+#else
+#pragma unroll
+        for (int sl = 0; sl < F_STAGE / 1024; ++sl) {
+            uint32_t off = (uint32_t)(sl * 1024 + lane * 16);
+            off = off < lastq ? off : lastq;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qrun + off),
+                                             (__attribute__((address_space(3))) void *)(stage + sl * 1024), 16, 0, 0);
+        }
+#endif
+#pragma unroll
+        for (int sl = 0; sl < F_STAGE / 1024; ++sl) {
+            uint32_t off = (uint32_t)(sl * 512 + lane * 8);
+            off = off < lasts ? off : lasts;
+            const uint32_t *sp = (const uint32_t *)(srun + off);
+            x.raws[sl] = make_uint2(sp[0], sp[1]);
+        }
+        return x;
+    };
+
+    // Results of a tile are STORED ONE TILE LATER, right behind the wait at the top of the loop: stores and loads
+    // retire through one in-order counter, so a store issued at the end of a tile would make that wait
+    // last until the store has reached memory (measured: 30 % of the kernel).
+    struct Pend { int64_t i; uint32_t slot_lo; int32_t pos, reflen; uint32_t ncig, cw0, cw1, cw2, status, flags, entry; bool simple, has; };
+    Pend pend{0, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, false, false};
+    auto store_pending = [&](const Pend &r) {
+        if (r.simple) {
+            uint32_t *home = out.new_cig + ((size_t)r.slot_lo + 3 * (size_t)r.i);
+            if (r.ncig > 0u) home[0] = r.cw0;
+            if (r.ncig > 1u) home[1] = r.cw1;
+            if (r.ncig > 2u) home[2] = r.cw2;
+            if (out.new_pos) out.new_pos[r.i] = r.pos;
+            if (out.new_ncig) out.new_ncig[r.i] = r.ncig;
+            if (out.ref_len) out.ref_len[r.i] = r.reflen;
+            if (out.trim_flags) out.trim_flags[r.i] = (uint8_t)r.flags;
+            if (out.status) out.status[r.i] = (uint8_t)r.status;
+        }
+        // hand-over to the general pass: one reservation per wave
+        const unsigned long long m = __ballot(r.has);
+        if (m) {
+            uint32_t gb = 0;
+            if (lane == 0) gb = __hip_atomic_fetch_add((lds_u32 *)&L.gcount, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            gb = __shfl(gb, 0);
+            if (r.has) glist[(size_t)rb + gb + __popcll(m & ((1ull << lane) - 1ull))] = r.entry;
+        }
+    };
+
+    int64_t i0 = wbeg, i1 = wbeg;
+    Hdr hA = load_hdr(i0), hB{0, 0, 0u, 0u, 0u, 0u, 0u};
+    uint32_t m0A = 0, m0B = 0;
+    Geo gA = geometry(hA, i0, m0A), gB = gA;
+    L2 xA{}, xB{};
+    xA = issue_l2(hA, gA, m0A);
+    i1 = i0 + gA.ntake;
+    hB = load_hdr(i1);
+    while (i0 < wend) {
+        const int64_t i = i0 + lane;
+        const Hdr h = hA;
+        const Geo g = gA;
+        const int32_t pos = h.pos, tlen = h.tlen;
+        const uint32_t lseq = h.lseq, flag = h.flag, c0 = h.c0, c1 = h.c1, o8 = h.o8;
+        const uint32_t np = g.np;
+        const bool solo = g.solo, taken = g.taken, fastq = g.fastq, in_ref = g.in_ref;
+        const int ntake = g.ntake;
+        const uint32_t w0 = xA.w0;
+        const int32_t tabL = xA.tabL, tabR = xA.tabR;
+        // ---- rows: slot k of the lane holds piece (k + rot) mod np of its read (slots >= np: a copy of the last
+        // piece and an index past the read, which every range test below excludes) -------------------------------
         const uint32_t rot = (uint32_t)lane % np;
         const uint8_t *qrow = rd.qual + (int64_t)o8 * 8;
         const uint8_t *srow = rd.seq + (int64_t)o8 * 4;
+        const uint32_t lrow = fastq ? g.row : 0u;
         uint4 q16[F_NP];
         uint2 s8[F_NP];
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the DMA of this tile's qualities has landed, its other loads too
+        F_STAMP(1);
+#ifdef AMP_F_NODMA
+#pragma unroll
+        for (int sl = 0; sl < F_STAGE / 512; ++sl) *(lds_u32x2 *)(stage + sl * 512 + lane * 8) = amp_u32x2{xA.rawq[sl].x, xA.rawq[sl].y};
+#endif
+        wave_sync();
 #pragma unroll
         for (int k = 0; k < F_NP; ++k) {
             uint32_t p = (uint32_t)k + rot;
             p = p >= np ? p - np : p;
             p = (uint32_t)k < np ? p : np - 1u;
-            const uint2 a = *(const uint2 *)(qrow + p * 16u), b = *(const uint2 *)(qrow + p * 16u + 8u);
+            const lds_u8 *src = stage + lrow + p * 16u;
+            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8);
             q16[k] = make_uint4(a.x, a.y, b.x, b.y);
-            s8[k] = *(const uint2 *)(srow + p * 8u);
         }
-        const bool simple = shortq && c1 - c0 == 1u && is_simple_cigar(1, w0, (int32_t)lseq);
+        wave_sync();
+#pragma unroll
+        for (int sl = 0; sl < F_STAGE / 1024; ++sl) *(lds_u32x2 *)(stage + sl * 512 + lane * 8) = amp_u32x2{xA.raws[sl].x, xA.raws[sl].y};
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < F_NP; ++k) {
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
+            p = (uint32_t)k < np ? p : np - 1u;
+            const lds_u8 *src = stage + (lrow >> 1) + p * 8u;
+            s8[k] = make_uint2(*(const lds_u32 *)src, *(const lds_u32 *)(src + 4));
+        }
+        wave_sync();                                 // every lane has its rows: the staging buffer may be overwritten
+        store_pending(pend);                         // the previous tile's results
+        // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------
+        const bool simple = fastq && c1 - c0 == 1u && is_simple_cigar(1, w0, (int32_t)lseq);
         const bool rev = (flag & 0x10u) != 0;
         TrimState ts{pos, 1, 0u, 0};
         SimpleCig sc{w0 & 15u, 0, (int32_t)lseq, 0};
@@ -196,6 +347,14 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
         const int32_t first = !scan ? 0 : (rev || qlen < W) ? lo : lo + qlen - W + 1;
         const int32_t tab = first & ~7;
         const uint2 tw0 = *(const uint2 *)(qrow + tab), tw1 = *(const uint2 *)(qrow + tab + 8);
+        // ---- next tile: its bytes start moving now, its header was loaded during the previous tile.  No branch
+        // around these loads (behind the wave's last tile they fetch the first bytes of the batch): a branch would
+        // make the compiler wait for everything in flight at its end ------------------------------------------------
+        gB = geometry(hB, i1, m0B);
+        xB = issue_l2(hB, gB, m0B);
+        const int64_t i2 = i1 + gB.ntake;
+        const Hdr hC = load_hdr(i2);
+        F_STAMP(2);          // staged, rows in registers, primer clips, next tile issued
 
         // ---- sliding-window scan: first failing window start (forward) / last failing window end (reverse) --
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
@@ -220,9 +379,12 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             }
         }
 
+        F_STAMP(3);          // primer clips + window scan
         // ---- quality clip, outputs (A:589-686) ------------------------------------------------------------------
-        bool general = valid && !simple;
-        bool counted = false;
+        bool general = (taken || (solo && lane == 0)) && !simple;
+        bool counted = false, stored = false;
+        uint32_t ncig = 0, cw[3] = {0u, 0u, 0u};
+        int32_t reflen = 0;
         if (simple) {
             // the read's first quality byte (0xFF = QUAL '*') sits in the slot that holds piece 0: slot (np - rot) mod np
             uint32_t fb = q16[0].x;
@@ -249,26 +411,19 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
                     }
                     trim_quality_apply_simple(ts, rev, iq, qlen, sc);
                 }
-                const size_t slot = (size_t)c0 + 3 * (size_t)i;
-                uint32_t ncig = 0;
-                int32_t reflen = 0;
                 if (!ts.err) {
-                    uint32_t *home = out.new_cig + slot;
-                    if (sc.a > 0) home[ncig++] = ((uint32_t)sc.a << 4) | OP_S;
-                    if (sc.m > 0) home[ncig++] = ((uint32_t)sc.m << 4) | sc.op;
-                    if (sc.c > 0) home[ncig++] = ((uint32_t)sc.c << 4) | OP_S;
+                    if (sc.a > 0) cw[ncig++] = ((uint32_t)sc.a << 4) | OP_S;
+                    if (sc.m > 0) cw[ncig++] = ((uint32_t)sc.m << 4) | sc.op;
+                    if (sc.c > 0) cw[ncig++] = ((uint32_t)sc.c << 4) | OP_S;
                     reflen = sc.m > 0 ? sc.m : 1;
                 }
-                if (out.new_pos) out.new_pos[i] = ts.pos;
-                if (out.new_ncig) out.new_ncig[i] = ncig;
-                if (out.ref_len) out.ref_len[i] = reflen;
-                if (out.trim_flags) out.trim_flags[i] = ts.err ? (uint8_t)0 : (uint8_t)ts.flags;
-                if (out.status) out.status[i] = (uint8_t)ts.err;
+                stored = true;
                 if (ts.err) ++n_err;
                 counted = !ts.err && P.do_count;
             }
         }
 
+        F_STAMP(4);          // quality clip, outputs
         // ---- counting (A:709-753 for a read without indels) -----------------------------------------------------
         uint32_t redo = 0;                        // pieces (slots) the careful loop has to do
         const int32_t qa = counted ? sc.a : 0, qb = counted ? sc.a + sc.m : 0;
@@ -312,6 +467,7 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
                 }
             }
         }
+        F_STAMP(5);          // counting
         if (__ballot(redo != 0u)) {
             // careful loop (rare): bases of the flagged pieces one by one, straight from memory
             bool bad = false;
@@ -328,7 +484,7 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
                         const int32_t rp = ts.pos + (q - qa);
                         const uint32_t d = (uint32_t)(rp - win_base);
                         if (col > 4u || (uint32_t)rp >= G) bad = true;
-                        else if (d < (uint32_t)F_W) lds_add(win + rep * (uint32_t)F_REPW + col * F_W + d, 1u);
+                        else if (d < (uint32_t)F_W && col < (uint32_t)F_NPL) lds_add(win + rep * (uint32_t)F_REPW + col * F_W + d, 1u);
                         else atomicAdd(&counts[(size_t)rp * AMP_NSYM + col], 1u);
                     }
                 }
@@ -338,24 +494,22 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             redo = 0u;
         }
 
-        // ---- hand-over to the general pass: one reservation per wave ---------------------------------------
+        // ---- results and hand-over to the general pass: kept for the next turn of the loop ---------------------------
         {
             uint32_t entry = 0;
             bool has = false;
             if (general) { entry = (uint32_t)i; has = true; }
             else if (counted && redo) { entry = (uint32_t)i | GL_STATUS_ONLY; has = true; }   // a base could not be counted: exact status wanted
-            const unsigned long long m = __ballot(has);
-            if (m) {
-                uint32_t gb = 0;
-                if (lane == 0) gb = __hip_atomic_fetch_add((lds_u32 *)&L.gcount, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                gb = __shfl(gb, 0);
-                if (has) glist[(size_t)rb + gb + __popcll(m & ((1ull << lane) - 1ull))] = entry;
-            }
+            pend = Pend{i, c0, ts.pos, reflen, ncig, cw[0], cw[1], cw[2], (uint32_t)ts.err, ts.err ? 0u : ts.flags, entry, stored, has};
         }
+        F_STAMP(6);          // careful loop, hand-over
+        hA = hB; gA = gB; xA = xB; m0A = m0B; hB = hC;
+        i0 = i1; i1 = i2;
     }
+    store_pending(pend);
 
     __syncthreads();
-    for (int i = tid; i < AMP_NSYM * F_W; i += F_WAVES * 64) {
+    for (int i = tid; i < F_NPL * F_W; i += F_WAVES * 64) {
         uint32_t v = 0;
 #pragma unroll
         for (int r = 0; r < F_REP; ++r) v += win[r * F_REPW + i];
@@ -365,6 +519,7 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
+    F_STAMP_OUT;
     if (tid == 0) gcnt[blockIdx.x] = L.gcount;
 }
 

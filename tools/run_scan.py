@@ -23,6 +23,11 @@ ms = []
 for it in range(a.iters):
     e.reset(); e.process_device(rd, 0, dev_out); e.sync(); ms.append(e.last_kernel_ms())
 print("variant %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.depth, n), ["%.3f/%.3f" % m for m in ms])
+if os.environ.get("AMP_STAMPS"):
+    dc = e.debug_counters()
+    tot = float(sum(int(x) for x in dc[8:15])) or 1.0
+    print("phase shares (header wait, bytes wait, staging, clips+scan, qclip+outputs, count, careful+handover):",
+          ["%.1f%%" % (100.0 * int(x) / tot) for x in dc[8:15]], "cycles/tile-wave %.0f" % (tot / a.iters / ((n + 63) // 64)))
 if a.check:
     from oracle import oracle
     hb = b.to_host()
