@@ -1014,7 +1014,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     const size_t dlist_words = ((size_t)tg.grid + 1) * (size_t)tg.tpb * TILE;
-    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid + (size_t)n + 64 : 0;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
@@ -1031,7 +1031,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     if (!out.new_ncig) { out.new_ncig = extra; }
     extra += n;
     if (!out.new_cig) { out.new_cig = extra; extra += slots; }
-    uint32_t *glist = extra, *gcnt = glist + (size_t)fg.grid * (size_t)fg.rpb, *gdense = gcnt + fg.grid;
+    uint32_t *glist = extra, *gcnt = glist + (size_t)fg.grid * (size_t)fg.rpb, *gdense = gcnt + fg.grid * F_WAVES;
     GenGeo *geo = (GenGeo *)(gdense + ((n + 3) & ~(int64_t)3));
     const EventBuf eb{c->events.as<amp_ins_event>(), c->d_ctr, c->d_ins_at, (long long)c->ev_cap};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1048,7 +1048,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, gdense, geo, (uint32_t)tg.grid);
+        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)tg.grid);
         HIPCHK(c, hipGetLastError());
         k_tile<false, false, true><<<(unsigned)tg.grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
                                                                                     gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
