@@ -195,6 +195,43 @@ __device__ int count_regular_skip(const KParams &P, const CB &cig, int n, int32_
     return 0;
 }
 
+// qualities through an 8-byte register cache (reads start on 8-byte boundaries): the bases of an
+// insertion cost one or two memory round trips instead of one each
+struct QualAt {
+    const uint8_t *q;
+    mutable int32_t blk = -1;
+    mutable uint32_t lo = 0, hi = 0;
+    __device__ uint32_t operator()(int32_t k) const {
+        if ((k >> 3) != blk) {
+            blk = k >> 3;
+            const uint2 v = *(const uint2 *)(q + (int64_t)blk * 8);
+            lo = v.x; hi = v.y;
+        }
+        return (((k & 4) ? hi : lo) >> ((k & 3) * 8)) & 0xFFu;
+    }
+};
+
+
+// Sink of the in-tile indel walk: '-' counts go through the block's window, insertion events are staged in the
+// wave's (by then idle) segment table and leave for the list with ONE reservation per tile (a returning global
+// atomic per event serialises in L2).  Events beyond the staging capacity take the slow path.
+constexpr uint32_t T_EVCAP = 144;     // = G_WORDS * T_SEGCAP / 4 events of four words
+struct TileEvSink {
+    const TileCtx &t;
+    uint32_t read;
+    lds_u32 *stage, *cursor;
+    __device__ void add(int32_t r, uint32_t col) { tile_add(t, r, col); }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+        const uint32_t k = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k < T_EVCAP) {
+            stage[k * 4] = (uint32_t)pos; stage[k * 4 + 1] = read; stage[k * 4 + 2] = (uint32_t)lo; stage[k * 4 + 3] = (uint32_t)hi;
+            atomicAdd(&t.eb.ins_at[pos], 1u);
+        } else {
+            t.eb.record(pos, read, lo, hi);
+        }
+    }
+};
+
 // A(1) C(2) G(4) T(8) -> 0..3, N(15) -> 4, anything else -> 15
 __device__ __forceinline__ uint32_t col_of_code(uint32_t code) {
     const uint32_t lo = 0xFFF2F10Fu;  // codes 0..7
@@ -803,6 +840,36 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         wave_sync();
         AMP_STAMP(3);
 
+        // ---- deletions, reference skips and insertion events of regular reads (A:714-715, A:730-748), lane = read:
+        // the skip-ahead walk over the final CIGAR, which is still in the lane's LDS column; '-' goes through the
+        // window, events through the idle segment table and out with one reservation for the whole tile --------
+        bool indel_err = false;
+        if (__ballot(defer_indels)) {
+            lds_u32 *const evcur = st + S_CB2 * TILE;                 // (the chunk bases are no longer needed)
+            if (lane == 0) *evcur = 0u;
+            wave_sync();
+            if (defer_indels) {
+                TileEvSink sink{tc, (uint32_t)(read_base + (uint64_t)i), seg, evcur};
+                int e1 = 0, e2 = 0;
+                const int32_t qs2 = query_alignment_start(cur, ts.n, lseq, e1), qe2 = query_alignment_end(cur, ts.n, lseq, e2);
+                indel_err = count_regular_skip(P, cur, ts.n, ts.pos, lseq, qs2, qe2, QualAt{qual}, sink) != 0;   // exact status: second pass
+            }
+            wave_sync();
+            const uint32_t nev_all = *evcur;
+            const uint32_t nev = nev_all < T_EVCAP ? nev_all : T_EVCAP;
+            if (nev) {
+                const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
+                unsigned long long eb0 = 0;
+                if (lane == 0) eb0 = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)nev);
+                eb0 = __shfl(eb0, 0);
+                for (uint32_t k = (uint32_t)lane; k < nev; k += 64u)
+                    if ((long long)(eb0 + k) < eb.cap)
+                        eb.ev[(size_t)shard * (size_t)eb.cap + eb0 + k] =
+                            amp_ins_event{(int32_t)seg[k * 4], seg[k * 4 + 1], (int32_t)seg[k * 4 + 2], (int32_t)seg[k * 4 + 3]};
+            }
+            wave_sync();
+        }
+
         // ---- status / deferral (lane = read): one list reservation per wave -------------------------
         {
             uint32_t status = (uint32_t)ts.err;
@@ -812,8 +879,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 if (status_wanted) { entry = (uint32_t)i | DEFER_STATUS_ONLY; has = true; status = 0; }
                 else if (defer_full) { entry = (uint32_t)i; has = true; status = 0; }
                 else if (!status && P.do_count) {
-                    if (defer_indels) { entry = (uint32_t)i | DEFER_INDELS; has = true; }
-                    if (st[S_ERR * TILE + lane]) { entry |= (uint32_t)i | DEFER_STATUS_ONLY; has = true; }
+                    if (st[S_ERR * TILE + lane] || indel_err) { entry = (uint32_t)i | DEFER_STATUS_ONLY; has = true; }
                 }
                 if (status) ++n_err;
                 if (out.status && !status_wanted) out.status[i] = (uint8_t)status;

@@ -317,22 +317,6 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
 constexpr int D_MAXOPS = 20;
-// qualities through an 8-byte register cache (reads start on 8-byte boundaries): the bases of an
-// insertion cost one or two memory round trips instead of one each
-struct QualAt {
-    const uint8_t *q;
-    mutable int32_t blk = -1;
-    mutable uint32_t lo = 0, hi = 0;
-    __device__ uint32_t operator()(int32_t k) const {
-        if ((k >> 3) != blk) {
-            blk = k >> 3;
-            const uint2 v = *(const uint2 *)(q + (int64_t)blk * 8);
-            lo = v.x; hi = v.y;
-        }
-        return (((k & 4) ? hi : lo) >> ((k & 3) * 8)) & 0xFFu;
-    }
-};
-
 template <class Sink>
 __device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
                                       const EventBuf &eb, bool status_only, LdsCig256 &cur, LdsCig256 &tmp, uint32_t c0, int n,
@@ -1013,7 +997,12 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const FastGrid fg = fast_grid(n, c->n_cu);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
-    const size_t dlist_words = ((size_t)tg.grid + 1) * (size_t)tg.tpb * TILE;
+    // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without
+    // tiles would still have to be placed on a CU one after the other), tiles per block decided on the device
+    const int64_t gen_grid = std::min<int64_t>(tg.grid, 4 * (int64_t)c->n_cu);
+    const int64_t n_tiles_max = (n + TILE - 1) / TILE;
+    const int64_t gen_tpb_max = (((n_tiles_max + gen_grid - 1) / gen_grid + T_WAVES - 1) / T_WAVES) * T_WAVES;
+    const size_t dlist_words = std::max(((size_t)tg.grid + 1) * (size_t)tg.tpb, (size_t)(n_tiles_max + gen_tpb_max + T_WAVES)) * TILE;
     const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
@@ -1048,12 +1037,12 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)tg.grid);
+        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid);
         HIPCHK(c, hipGetLastError());
-        k_tile<false, false, true><<<(unsigned)tg.grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
+        k_tile<false, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
                                                                                     gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
         HIPCHK(c, hipGetLastError());
-        k_deferred_light<<<(unsigned)((tg.grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo,
+        k_deferred_light<<<(unsigned)((gen_grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo,
                                                                                (long long)tg.grid);
         HIPCHK(c, hipGetLastError());
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(

@@ -28,6 +28,15 @@ def shard_bounds(batch, world):
     return cuts
 
 
+def shard_bounds_from_lseq(lseq, world):
+    """shard_bounds for a batch known by its read lengths only (device-resident batches)."""
+    cum = np.concatenate([[0], np.cumsum(np.asarray(lseq).astype(np.int64))])
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, total * k // world, side="left")) for k in range(world + 1)]
+    cuts[0], cuts[-1] = 0, int(len(lseq))
+    return cuts
+
+
 def reduce_table(dist, table, dst=0):
     """Sum the device table (torch int32/uint32-as-int32 tensor) onto ``dst``."""
     dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)

@@ -31,6 +31,14 @@ class DeviceBatch:
                                self.seq_off8.data_ptr(), self.seq.data_ptr(), self.qual.data_ptr(),
                                self.n_cig, self.n_bases_padded)
 
+    def rows(self, lo, hi):
+        """Rows [lo, hi) as a batch that shares this one's CIGAR / base / quality arrays (offsets stay absolute:
+        the kernels index those arrays through cig_off32 / seq_off8).  n_cig is the END offset of the last row, so
+        that an output CIGAR array of n_cig + 3 n words has room for the slots cig_off32[i] + 3 i."""
+        return DeviceBatch(hi - lo, self.pos[lo:hi], self.flag[lo:hi], self.tlen[lo:hi], self.lseq[lo:hi],
+                           self.cig_off32[lo:hi + 1], self.cig, self.seq_off8[lo:hi + 1], self.seq, self.qual,
+                           int(self.cig_off32[hi].item()), self.n_bases_padded)
+
     def to_host(self, lo=0, hi=None):
         """Rows [lo, hi) as a host ReadBatch (for the CPU baseline / parity check)."""
         hi = self.n if hi is None else hi

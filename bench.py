@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the trim + pileup + call hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--depth D]
+    python bench.py --gpus N --steps K --warmup W [--depth D] [--strong]
 
 One "step" = one pass of the whole hot path over one synthetic batch that is already resident
 in HBM: reset the device table, run the trim + pileup kernels over every read of the batch
@@ -14,14 +14,22 @@ step is complete when the timed region ends.  --no-pipeline runs them strictly o
 
 Workload (config.workload): BASELINE.json's metric is quoted on a ~30 kb reference at 10k x
 depth: 29,903 nt synthetic genome, ARTIC-style 98-amplicon primer scheme, 150 bp paired reads,
-1,993,533 reads per GPU (SURVEY.md section 8(d) generator, built on the GPU with torch).  With
-N GPUs the genome's amplicons are range-partitioned by coordinate over the ranks and every rank
-holds a full-size batch of its own range (weak scaling: the job is N x 10k x deep); counts are
-stitched with one reduce of the 7 x 29,903 uint32 device table.
+1,993,533 reads per GPU (SURVEY.md section 8(d) generator, built on the GPU with torch).
+  default (weak scaling): with N GPUs the genome's amplicons are range-partitioned by coordinate
+      over the ranks and every rank holds a full-size batch of its own range (the job is N x D deep)
+  --strong (BASELINE config 4): ONE job of depth D; its coordinate-sorted reads are cut into N
+      contiguous slices of equal base counts (parallel.shard_bounds), rank r processes slice r, and
+      rank 0 asserts that the all-reduced table is bit-identical to the table of the whole job
+      processed on one GPU.
+Either way the counts are stitched with one all-reduce of the 7 x 29,903 uint32 device table.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
-  roofline:     algorithmic bytes of the CIGAR-scan kernel / its HIP-event duration vs 8 TB/s
-  cpu_baseline: the C restatement in oracle/ timed on this host's cores on the same batch
+  roofline:     algorithmic bytes of the CIGAR-scan pass / its HIP-event duration vs 8 TB/s.  The
+                scan pass is what amp_process_batch_device launches: k_fast (simple reads), k_gcompact,
+                k_tile<LIST> (the other reads), k_deferred_light / k_deferred_heavy
+  cpu_baseline: the C restatement in oracle/ timed on this host's cores on the same batch, plus the
+                pure-Python restatement on a 100 k-read subsample
+  e2e:          file-to-file rates outside the timed region (host pointers, BAM -> calls, BAM -> BAM)
 """
 import argparse
 import json
@@ -36,6 +44,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+SCAN_KERNELS = {4: "scan pass: k_fast + k_gcompact + k_tile<LIST> + k_deferred_light + k_deferred_heavy",
+                2: "scan pass: k_tile + k_deferred_light + k_deferred_heavy",
+                3: "scan pass: k_trim + k_scan + k_tile<SPLIT> + k_deferred_light + k_deferred_heavy", 1: "k_reads_lane"}
 
 
 def main():
@@ -48,11 +59,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=10000, help="mean coverage per GPU (10000 -> 1,993,533 reads)")
-    ap.add_argument("--cpu-passes", type=int, default=12, help="passes of the CPU baseline over the batch (0 = skip)")
+    ap.add_argument("--depth", type=int, default=10000, help="mean coverage (10000 -> 1,993,533 reads): per GPU, or of the whole job with --strong")
+    ap.add_argument("--strong", action="store_true", help="BASELINE config 4: one job of --depth partitioned over the ranks (strong scaling)")
+    ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
     ap.add_argument("--variant", type=int, default=4)
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,11 +89,20 @@ def main():
     primers, amps = synth.make_artic_scheme()
     G = int(genome.size)
     ref_seq = synth.genome_string(genome)
-    n_reads = synth.reads_for_depth(args.depth)
-    # range partition by coordinate: rank r owns a contiguous run of amplicons
-    a_lo, a_hi = parallel.amplicon_range(amps.shape[0], rank, world)
+    job_reads = synth.reads_for_depth(args.depth)
     t_gen = time.time()
-    batch = synth_torch.make_amplicon_batch_device(genome, amps[a_lo:a_hi], n_reads, seed=1000 + rank, device=dev)
+    if args.strong:
+        # the SAME job on every rank (same seed), cut by base count; rank r keeps rows [lo, hi)
+        whole = synth_torch.make_amplicon_batch_device(genome, amps, job_reads, seed=1000, device=dev)
+        cuts = parallel.shard_bounds_from_lseq(whole.lseq.cpu().numpy().view(np.uint32), world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        batch = whole.rows(lo, hi)
+    else:
+        # range partition by coordinate: rank r owns a contiguous run of amplicons and a full-size batch of them
+        a_lo, a_hi = parallel.amplicon_range(amps.shape[0], rank, world)
+        whole = None
+        batch = synth_torch.make_amplicon_batch_device(genome, amps[a_lo:a_hi], job_reads, seed=1000 + rank, device=dev)
+    n_reads = batch.n
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
@@ -91,7 +113,7 @@ def main():
     class Slot:
         """One in-flight step: its own HIP stream, engine (device table, event list, scratch) and outputs."""
 
-        def __init__(self):
+        def __init__(self, b=batch):
             self.stream = torch.cuda.Stream(device=dev)
             self.eng = eng = lib.Engine(G, device=local_rank)
             eng.set_kernel_variant(args.variant)
@@ -101,14 +123,15 @@ def main():
             eng.set_primers(mn, mx, mpl)
             eng.set_params(20, 4, True, True)
             eng.set_reference(ref_seq)
-            eng.reserve_events(max(1 << 20, n_reads // 4))
+            eng.reserve_events(max(1 << 20, b.n // 4))
+            self.rd = b.struct()
             self.out = {
-                "new_pos": torch.zeros(n_reads, dtype=torch.int32, device=dev),
-                "new_ncig": torch.zeros(n_reads, dtype=torch.int32, device=dev),
-                "new_cig": torch.zeros(batch.n_cig + 3 * n_reads, dtype=torch.int32, device=dev),
-                "ref_len": torch.zeros(n_reads, dtype=torch.int32, device=dev),
-                "trim_flags": torch.zeros(n_reads, dtype=torch.uint8, device=dev),
-                "status": torch.zeros(n_reads, dtype=torch.uint8, device=dev),
+                "new_pos": torch.zeros(b.n, dtype=torch.int32, device=dev),
+                "new_ncig": torch.zeros(b.n, dtype=torch.int32, device=dev),
+                "new_cig": torch.zeros(b.n_cig + 3 * b.n, dtype=torch.int32, device=dev),
+                "ref_len": torch.zeros(b.n, dtype=torch.int32, device=dev),
+                "trim_flags": torch.zeros(b.n, dtype=torch.uint8, device=dev),
+                "status": torch.zeros(b.n, dtype=torch.uint8, device=dev),
             }
             self.dev_out = abi.AmpTrimOut(*[self.out[k].data_ptr() for k in
                                             ("new_pos", "new_ncig", "new_cig", "ref_len", "trim_flags", "status")])
@@ -117,7 +140,7 @@ def main():
             eng = self.eng
             ev = eng.events()
             keep = np.isin(ev["ref_pos"], np.fromiter(positions, np.int64, len(positions)))
-            strings = eng.event_strings_device(rd, ev[keep]) if keep.any() else []
+            strings = eng.event_strings_device(self.rd, ev[keep]) if keep.any() else []
             pairs = list(zip(ev["ref_pos"][keep].tolist(), strings))
             if dist is not None:      # every rank sees the same positions (tables are all-reduced): symmetric exchange
                 pairs = parallel.allgather_relevant_events(dist, world, pairs)
@@ -128,7 +151,7 @@ def main():
     # kernels, reduce, calls, records, consensus string - before the timed region ends.
     depth = 1 if args.no_pipeline else 2
     slots = [Slot() for _ in range(depth)]
-    scan_ms = []
+    pass_ms, fast_ms = [], []
     last = {}
 
     def submit(k):
@@ -146,7 +169,8 @@ def main():
             last["call"] = res = calling.call(sl.eng, ref_seq, cp, sl.ins_provider)
             last["consensus"] = res.consensus_string("N")
             last["slot"] = sl
-        scan_ms.append(sl.eng.last_kernel_ms()[1])
+        t, s = sl.eng.last_kernel_ms()
+        pass_ms.append(t); fast_ms.append(s)
 
     def run(n):
         for k in range(n):
@@ -157,7 +181,7 @@ def main():
             finish(k)
 
     run(args.warmup)
-    del scan_ms[:]
+    del pass_ms[:], fast_ms[:]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -172,89 +196,150 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng, table, out_t = last["slot"].eng, last["slot"].table, last["slot"].out
-    # outside the timed region: the same kernel with nothing else on the GPU (the pipelined steps above
-    # overlap it with the previous step's small kernels and with the next scan, which stretches its
+    # outside the timed region: the same launches with nothing else on the GPU (the pipelined steps above
+    # overlap them with the previous step's small kernels and with the next scan, which stretches their
     # own duration while shortening the step)
-    solo_ms = []
-    if depth > 1:
-        for _ in range(5):
-            with torch.cuda.stream(last["slot"].stream):
-                eng.reset()
-                eng.process_device(rd, 0, last["slot"].dev_out)
-                eng.sync()
-            solo_ms.append(eng.last_kernel_ms()[1])
+    solo_pass, solo_fast = [], []
+    for _ in range(5):
+        with torch.cuda.stream(last["slot"].stream):
+            eng.reset()
+            eng.process_device(rd, 0, last["slot"].dev_out)
+            eng.sync()
+        t, s = eng.last_kernel_ms()
+        solo_pass.append(t); solo_fast.append(s)
+    if dist is not None:     # leave the engine with the reduced table again (the check below and the calls use it)
+        with torch.cuda.stream(last["slot"].stream):
+            parallel.allreduce_table(dist, table)
+        torch.cuda.synchronize()
 
     # ---- accounting (outside the timed region) ------------------------------------------------
     n_out = int(out_t["new_ncig"].sum().item())
     n_err = int((out_t["status"] != 0).sum().item())
     L = 150
-    alg_bytes = n_reads * (16 + (L + 1) // 2 + L + 8) + 4 * batch.n_cig + 4 * n_out + 6 * G * 4 + 2 * G * 4
-    k_ms = float(np.mean(scan_ms))
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # 16 B of per-read fields + CIGAR words in and out + packed bases + qualities + 8 B of per-read
+    # results, plus once per launch the count table written and the primer tables read
+    n_cig_in = int(batch.cig_off32[-1].item() - batch.cig_off32[0].item())
+    alg_bytes = n_reads * (16 + (L + 1) // 2 + L + 8) + 4 * n_cig_in + 4 * n_out + 6 * G * 4 + 2 * G * 4
+    k_ms = float(np.mean(pass_ms))
+    k_solo = float(np.mean(solo_pass))
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.isfile(tf):
-        traffic = json.load(open(tf)).get("depth%d" % args.depth)
+        traffic = json.load(open(tf)).get("depth%d_variant%d" % (args.depth, args.variant))
+
+    strong_check = None
+    if args.strong and rank == 0:
+        # bit-identity of the stitched table with the whole job on ONE GPU (A:896-915 is an order-free integer sum)
+        one = Slot(whole)
+        with torch.cuda.stream(one.stream):
+            one.eng.reset()
+            one.eng.process_device(one.rd, 0, one.dev_out)
+            one.eng.sync()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(one.table, table))
+        assert same, "the all-reduced table of %d slices differs from the table of the whole job on one GPU" % world
+        strong_check = "all-reduced table of %d slices == table of the whole %d-read job on one GPU (7 x %d uint32, bit-identical)" % (world, whole.n, G)
+        one.eng.close()
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_passes > 0:
+    if rank == 0 and world == 1 and args.cpu_passes >= 0:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle
         hb = batch.to_host()
-        # one thread: the checker pass (the GPU result of the last step must equal the oracle's on the same batch)
-        t1 = time.perf_counter()
-        ref = oracle.process(hb, G, mn, mx, mpl, 20, 4)
-        t1 = time.perf_counter() - t1
-        got = table.cpu().numpy().view(np.uint32)
-        assert np.array_equal(got[:G * 6].reshape(G, 6), ref.counts), "GPU count table differs from the oracle"
-        assert np.array_equal(out_t["new_pos"].cpu().numpy(), ref.trim.new_pos), "trimmed positions differ from the oracle"
-        assert int(got[G * 6:].sum()) == ref.events.size, "insertion events differ from the oracle"
-        # all host cores: reads sharded over threads (the C call releases the GIL), private tables summed
         # (a one-GPU box gets a 16-CPU share of its host, whatever the affinity mask says)
         cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("AMPLIPY_CPU_THREADS", "16")))
         cuts = [hb.n * k // cores for k in range(cores + 1)]
+        got = table.cpu().numpy().view(np.uint32)
+        h_pos = out_t["new_pos"].cpu().numpy()
 
-        def shard(k):
-            return oracle.process(hb, G, mn, mx, mpl, 20, 4, lo=cuts[k], hi=cuts[k + 1]).counts
+        def shard(k, check=False):
+            sb = hb.slice(cuts[k], cuts[k + 1])
+            r = oracle.process(sb, G, mn, mx, mpl, 20, 4, read_base=cuts[k])
+            if check:
+                assert np.array_equal(r.trim.new_pos, h_pos[cuts[k]:cuts[k + 1]]), "trimmed positions differ from the oracle"
+            return r.counts, r.events.size
 
+        # all host cores: reads sharded over threads (the C call releases the GIL), private tables summed.
+        # The first pass is the checker: the GPU result of the last step must equal the oracle's on the same batch.
         with ThreadPoolExecutor(cores) as pool:
+            t1 = time.perf_counter()
+            parts = list(pool.map(lambda k: shard(k, True), range(cores)))
+            t1 = time.perf_counter() - t1
+            total = np.sum([p[0] for p in parts], axis=0, dtype=np.uint32)
+            assert np.array_equal(got[:G * 6].reshape(G, 6), total), "GPU count table differs from the oracle"
+            assert int(got[G * 6:].sum()) == sum(p[1] for p in parts), "insertion events differ from the oracle"
+            passes = args.cpu_passes if args.cpu_passes > 0 else max(1, min(40, int(10.0 / max(t1, 1e-3))))
             t_cpu = time.perf_counter()
-            for _ in range(args.cpu_passes):
+            for _ in range(passes):
                 parts = list(pool.map(shard, range(cores)))
-                total = np.sum(parts, axis=0, dtype=np.uint32)
             t_cpu = time.perf_counter() - t_cpu
-        assert np.array_equal(total, ref.counts), "sharded CPU run differs from the single-thread run"
-        cpu = {"value": round(hb.n * args.cpu_passes / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "single_thread_value": round(hb.n / t1, 1),
+        # one thread, on a sample
+        ns = min(hb.n, 400000)
+        t_one = time.perf_counter()
+        oracle.process(hb.slice(0, ns), G, mn, mx, mpl, 20, 4)
+        t_one = time.perf_counter() - t_one
+        cpu = {"value": round(hb.n * passes / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "single_thread_value": round(ns / t_one, 1),
                "sample": "the full %d-read batch, %d passes of oracle/amplipy_oracle.c (trim + pileup) sharded by read over "
-                         "%d threads with private count tables summed at the end; single_thread_value = one pass on one thread"
-                         % (hb.n, args.cpu_passes, cores)}
+                         "%d threads with private count tables summed at the end (after one checking pass: GPU table, "
+                         "trimmed positions and event count equal the oracle's); single_thread_value = %d reads on one thread"
+                         % (hb.n, passes, cores, ns)}
+        try:
+            from oracle import py_restatement
+            npy = min(hb.n, 100000)
+            t_py = time.perf_counter()
+            pr = py_restatement.process(hb.slice(0, npy), G, mn, mx, mpl, 20, 4)
+            t_py = time.perf_counter() - t_py
+            ref_py = oracle.process(hb.slice(0, npy), G, mn, mx, mpl, 20, 4)
+            assert np.array_equal(pr, ref_py.counts), "pure-Python restatement differs from the C oracle"
+            cpu["python_restatement"] = {"value": round(npy / t_py, 1), "unit": "reads/s", "cores": 1,
+                                         "sample": "oracle/py_restatement.py (per-base interpreter loop, the shape of AmpliPy's own code) "
+                                                   "on the first %d reads; counts equal the C oracle's" % npy}
+        except ImportError:
+            pass
+
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            from tools import e2e_legs
+            e2e = e2e_legs.measure(batch, genome, primers, ref_seq, dev)
+        except Exception as ex:      # the legs are extras: never lose the bench line to them
+            e2e = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0:
-        total_reads = n_reads * world * args.steps
+        total_reads = n_reads * args.steps if not args.strong else job_reads * args.steps
+        if not args.strong:
+            total_reads *= world
         res = last["call"]
         line = {
-            "metric": "aligned reads/s through trim+pileup+call, 30 kb ref @ 10k x depth",
+            "metric": "aligned reads/s through trim+pileup+call, 30 kb ref @ %dk x depth" % (args.depth // 1000)
+                      if args.depth % 1000 == 0 else "aligned reads/s through trim+pileup+call, 30 kb ref @ %d x depth" % args.depth,
             "value": round(total_reads / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "synthetic 29,903 nt genome, 98-amplicon ARTIC-style primers, 150 bp paired reads, "
-                                   "%d x depth = %d reads per GPU, inputs resident in HBM" % (args.depth, n_reads),
+                                   + ("ONE job of %d x depth = %d reads cut into %d coordinate slices of equal base counts" % (args.depth, job_reads, world)
+                                      if args.strong else "%d x depth = %d reads per GPU" % (args.depth, n_reads))
+                                   + ", inputs resident in HBM",
                        "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
                        "parallelism": "coordinate-range partition x%d + one RCCL all-reduce of the count table per step" % world,
-                       "steps_in_flight": depth,
-                       "kernel_variant": args.variant, "error_reads": n_err,
-                       "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant},
-            "roofline": {"bound": "hbm", "kernel": "k_tile" if args.variant == 2 else "k_reads_lane",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+                       "steps_in_flight": depth, "kernel_variant": args.variant, "error_reads": n_err,
+                       "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant,
+                       "strong_check": strong_check},
+            "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
+                         "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 5),
-                         "kernel_ms_alone": round(float(np.mean(solo_ms)), 5) if solo_ms else round(k_ms, 5),
-                         "frac_alone": round(alg_bytes / (float(np.mean(solo_ms)) if solo_ms else k_ms) / 1e6 / HBM_PEAK_GBS, 5),
-                         "note": "kernel_ms / achieved / frac: HIP events around k_tile inside the timed region, where the "
-                                 "launches of two steps in flight overlap each other and the small kernels; "
-                                 "kernel_ms_alone / frac_alone: the same launch with the GPU to itself (5 launches after the timed region)"},
+                         "kernel_ms_alone": round(k_solo, 5),
+                         "frac_alone": round(alg_bytes / k_solo / 1e6 / HBM_PEAK_GBS, 5),
+                         "fast_kernel_ms_alone": round(float(np.mean(solo_fast)), 5),
+                         "note": "kernel_ms / achieved / frac: HIP events around ALL kernels of the scan pass (amp_process_batch_device) "
+                                 "inside the timed region, where two steps in flight overlap each other; kernel_ms_alone / frac_alone: "
+                                 "the same launches with the GPU to itself (5 passes after the timed region); fast_kernel_ms_alone: "
+                                 "the first kernel of the pass alone (k_fast for variant 4)"},
             "cpu_baseline": cpu,
+            "e2e": e2e,
             "gen_seconds": round(t_gen, 2),
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -82,3 +82,28 @@ def test_allele_ranking():
         total, order = oracle.rank_alleles(syms, cnt)
         assert total == rec["total"]
         assert [[cnt[i], syms[i]] for i in order] == [[a[0], a[2]] for a in rec["alleles"]]
+
+
+def test_python_restatement_equals_c_oracle_and_golden():
+    """oracle/py_restatement.py (the CPU-baseline leg with AmpliPy's own algorithmic shape) against the C oracle
+    and the reference-derived pileup fixture."""
+    from amplipy_amd import synth
+    from amplipy_amd.batch import ReadBatch
+    from oracle import py_restatement
+    g = H.load_json("pileup_5000.json.gz")
+    reads = [H.seg_from_dict(d) for d in g["reads"]]
+    b = ReadBatch.from_segments(reads)
+    mn, mx, mpl = oracle.find_overlapping_primers(g["ref_len"], g["primers"], g["offset"])
+    counts, events, trims = py_restatement.process_full(b, g["ref_len"], mn, mx, mpl, g["params"]["min_quality"], g["params"]["window"])
+    ref = oracle.process(b, g["ref_len"], mn, mx, mpl, g["params"]["min_quality"], g["params"]["window"])
+    assert np.array_equal(counts, ref.counts)
+    assert sorted(events) == sorted((int(e["ref_pos"]), int(e["read"]), int(e["q_from"]), int(e["q_to"])) for e in ref.events)
+    from amplipy_amd.segment import format_cigar
+    for i, (pos, cig, flags, reflen) in enumerate(g["trim"]):
+        assert (trims[i][0], format_cigar(trims[i][1]), list(trims[i][2])) == (pos, cig, flags), i
+    # mixed shapes (soft clips, indel-heavy CIGARs), no trimming
+    genome = synth.make_genome(); _, amps = synth.make_artic_scheme()
+    b2 = ReadBatch.from_segments(synth.make_mixed_segments(genome, amps, 600, seed=12))
+    none = np.full(genome.size, -1, np.int32)
+    c2 = py_restatement.process_full(b2, genome.size, none, none, 0, 20, 4, do_trim=False)[0]
+    assert np.array_equal(c2, oracle.process(b2, genome.size, do_trim=False).counts)

@@ -1,0 +1,82 @@
+"""File-to-file legs of bench.py's `e2e` object (run after the timed region; needs a GPU).
+
+  host_ptr_reads_per_s      amp_process_batch from host arrays: H2D staging + kernels + D2H of the per-read results
+  bam_to_calls_reads_per_s  the `variants` command on a BAM file: inflate + decode + H2D + kernels + calling + VCF
+  bam_to_bam_reads_per_s    the `aio` command: the same plus re-encoding and deflating the trimmed BAM, VCF, consensus
+All three are whole-call wall times on a bounded sample of the bench workload (the BAM is written from the first
+rows of the same synthetic batch with the package's own codec).
+"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def write_bam(path, hb, G):
+    from amplipy_amd import bamio
+    from amplipy_amd.batch import SEQ_NT16, unpack_nibbles
+    hdr = bamio.Header("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:SYN_REF\tLN:%d\n@PG\tID:sim\tPN:sim\n" % G, [("SYN_REF", G)])
+    w = bamio.AlignmentWriter(path, "wb", hdr)
+    lut = np.frombuffer(SEQ_NT16.encode(), np.uint8)
+    for i in range(hb.n):
+        o = int(hb.seq_off[i]); L = int(hb.lseq[i])
+        seq = lut[unpack_nibbles(hb.seq[o // 2:(o + L + 1) // 2], L)].tobytes().decode()
+        a, c = int(hb.cig_off[i]), int(hb.cig_off[i + 1])
+        w.write(bamio.Rec("r%d" % i, int(hb.flag[i]), 0, int(hb.pos[i]), 60, [(int(v) & 15, int(v) >> 4) for v in hb.cig[a:c]], 0,
+                          int(hb.pos[i]), int(hb.tlen[i]), seq, bytes(hb.qual[o:o + L])))
+    w.close()
+
+
+def measure(batch, genome, primers, ref_seq, dev, n_host=1000000, n_bam=150000):
+    from amplipy_amd import amplipy, lib
+    G = int(genome.size)
+    out = {}
+    mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
+    # ---- host pointers ----
+    nh = min(batch.n, n_host)
+    hb = batch.to_host(0, nh)
+    eng = lib.Engine(G)
+    eng.set_primers(mn, mx, mpl); eng.set_params(20, 4, True, True)
+    best = 1e9
+    for _ in range(3):
+        eng.reset()
+        t0 = time.perf_counter(); eng.process(hb); best = min(best, time.perf_counter() - t0)
+    eng.close()
+    out["host_ptr_reads_per_s"] = round(nh / best, 1)
+    out["host_ptr_sample"] = "%d reads, amp_process_batch (pageable host arrays in, per-read results out), best of 3" % nh
+    # ---- BAM legs ----
+    nb = min(batch.n, n_bam)
+    tmp = tempfile.mkdtemp(prefix="amp_e2e_")
+    inp = os.path.join(tmp, "in.bam")
+    write_bam(inp, batch.to_host(0, nb), G)
+    with open(os.path.join(tmp, "ref.fas"), "w") as f:
+        f.write(">SYN_REF\n" + ref_seq + "\n")
+    with open(os.path.join(tmp, "p.bed"), "w") as f:
+        f.write("".join("SYN_REF\t%d\t%d\tp%d\n" % (s, e, i) for i, (s, e, _) in enumerate(primers)))
+    log = sys.stderr
+    sys.stderr = open(os.devnull, "w")        # the commands log progress lines like the reference does
+    try:
+        t_aio = t_var = 1e9
+        for it in range(2):
+            outs = {k: os.path.join(tmp, "%s%d.%s" % (k, it, ext)) for k, ext in (("t", "bam"), ("v", "vcf"), ("c", "fas"))}
+            t0 = time.perf_counter()
+            amplipy.main(["aio", "-i", inp, "-p", os.path.join(tmp, "p.bed"), "-r", os.path.join(tmp, "ref.fas"),
+                          "-ot", outs["t"], "-ov", outs["v"], "-oc", outs["c"]])
+            t_aio = min(t_aio, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            amplipy.main(["variants", "-i", inp, "-r", os.path.join(tmp, "ref.fas"), "-o", os.path.join(tmp, "vv%d.vcf" % it)])
+            t_var = min(t_var, time.perf_counter() - t0)
+    finally:
+        sys.stderr.close()
+        sys.stderr = log
+    out["bam_to_bam_reads_per_s"] = round(nb / t_aio, 1)
+    out["bam_to_calls_reads_per_s"] = round(nb / t_var, 1)
+    out["bam_sample"] = ("%d-read BAM (%.1f MB) of the same workload; whole `aio` (trimmed BAM + VCF + consensus) and `variants` commands, "
+                         "best of 2, zlib level of the writer as shipped" % (nb, os.path.getsize(inp) / 1e6))
+    return out
