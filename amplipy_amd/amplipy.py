@@ -17,7 +17,7 @@ from os.path import isfile
 
 import numpy as np
 
-from . import AMPLIPY_VERSION, abi, bamio, calling, lib
+from . import AMPLIPY_VERSION, abi, bamio, calling, lib, parallel
 from .batch import ReadBatch
 from .insertions import EventStore
 
@@ -173,7 +173,18 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                 consensus_fn=None, primer_pos_offset=None, min_length=None, min_quality=None, sliding_window_width=None,
                 min_freq_consensus=None, min_freq_variants=None, min_depth_consensus=None, min_depth_variants=None,
                 unknown_symbol=None, include_no_primer=None, run_trim=False, run_variants=False, run_consensus=False,
-                device=0):
+                device=None):
+    """The reference's run_amplipy (AmpliPy.py:774-963) on the MI355X engine.
+
+    One process drives one GPU.  Under ``torchrun`` (WORLD_SIZE > 1, or AMPLIPY_FORCE_DIST=1 for a one-rank
+    rehearsal) the job is range-partitioned: rank r takes the r-th contiguous run of BAM records (coordinate
+    order), every rank's count table is summed with ONE all-reduce over RCCL (parallel.allreduce_table), the
+    insertion alleles of the flagged positions are exchanged, and rank 0 writes the VCF / consensus.  A trimmed
+    BAM is written per rank (``<name>.part<rank>.bam``; the parts concatenate to the single-GPU file's records).
+    """
+    dist, rank, world = parallel.init_from_env()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if dist is not None else 0
     # argument checks and banner: AmpliPy.py:836-866
     if primer_pos_offset is not None and primer_pos_offset < 0:
         error("Primer position offset must be non-negative: %s" % primer_pos_offset)
@@ -204,6 +215,15 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         ref_id, ref_seq = load_ref_genome(reference_fn)
     G = len(ref_seq)
     eng = lib.Engine(G, device=device)
+    table = None
+    if dist is not None:
+        import torch
+        torch.cuda.set_device(device)
+        table = torch.zeros(G * 7, dtype=torch.int32, device="cuda:%d" % device)   # counts + insertion tally
+        eng.bind_counts(table.data_ptr())
+        if run_trim and trimmed_reads_fn is not None and world > 1:
+            root, ext = os.path.splitext(trimmed_reads_fn)
+            trimmed_reads_fn = "%s.part%d%s" % (root, rank, ext)
     if primer_fn is not None:
         print_log("Loading primers: %s" % primer_fn)
         primers = load_primers(primer_fn)
@@ -223,7 +243,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         if native is None:
             reader, writer = open_alignment_files(trimmed_reads_fn, None)
     vcf = None
-    if variants_fn is not None:
+    if variants_fn is not None and rank == 0:
         print_log("Output variants VCF: %s" % variants_fn)
         vcf = VcfWriter(variants_fn, ref_id)
     do_count = run_variants or run_consensus
@@ -281,8 +301,9 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                             werr.append(e)
             wthread = threading.Thread(target=_writer, daemon=True); wthread.start()
         try:
-            for first in range(0, src.n_records, NATIVE_BATCH_READS):
-                count = min(NATIVE_BATCH_READS, src.n_records - first)
+            rec_lo, rec_hi = (src.n_records * rank) // world, (src.n_records * (rank + 1)) // world   # this rank's records
+            for first in range(rec_lo, rec_hi, NATIVE_BATCH_READS):
+                count = min(NATIVE_BATCH_READS, rec_hi - first)
                 batch, _ = src.decode(first, count)
                 for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
                     if s_i:
@@ -321,6 +342,8 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                 print_log("Processed %d reads..." % s_i)
             if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
                 continue
+            if world > 1 and s_i % world != rank:              # text input has no record index: deal the reads out
+                continue
             pending.append(rec)
             if len(pending) >= BATCH_READS:
                 flush()
@@ -336,7 +359,18 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                                  min_freq_variants if min_freq_variants is not None else 0,
                                  run_consensus, run_variants)
         eng.set_reference(ref_seq)
-        res = calling.call(eng, ref_seq, cp, lambda positions: calling.tallies_from_events(ins_store.pairs(positions), positions))
+        if dist is not None:
+            eng.sync()
+            parallel.allreduce_table(dist, table)      # the ONE collective of the run: every rank now holds the job's table
+
+        def ins_tallies(positions):
+            pairs = ins_store.pairs(positions)
+            if dist is not None:                       # all ranks flag the same positions (same table): symmetric exchange
+                pairs = parallel.allgather_relevant_events(dist, world, pairs)
+            return calling.tallies_from_events(pairs, positions)
+        res = calling.call(eng, ref_seq, cp, ins_tallies)
+        if rank != 0:
+            run_variants = run_consensus = False       # rank 0 writes the outputs
         if run_variants:
             for r in res.records:
                 vcf.write(r)
@@ -346,6 +380,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             f.write(">sample\n%s\n" % res.consensus_string(unknown_symbol))
             f.close()
     eng.close()
+    parallel.finish(dist)
     if s_i is None:
         raise NameError("name 's_i' is not defined")       # the reference's behaviour on an empty input (:963)
     print_log("Finished Processing %d reads" % s_i)

@@ -13,6 +13,33 @@ from __future__ import annotations
 import numpy as np
 
 
+def init_from_env():
+    """(dist, rank, world) for the calling process: torch.distributed over RCCL (backend "nccl"; "gloo" without a GPU)
+    when launched by torchrun with WORLD_SIZE > 1 or when AMPLIPY_FORCE_DIST=1, else (None, 0, 1)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and os.environ.get("AMPLIPY_FORCE_DIST", "0") != "1":
+        return None, 0, 1
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        if torch.cuda.is_available():
+            dev = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, rank, world
+
+
+def finish(dist):
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def amplicon_range(n_amplicons, rank, world):
     """Contiguous run of amplicons owned by ``rank`` (coordinate-range partition)."""
     return (n_amplicons * rank) // world, (n_amplicons * (rank + 1)) // world

@@ -438,3 +438,50 @@ def test_randomised_parameters_and_read_shapes(runner, seed):
     ok = np.nonzero(a.trim.status == 0)[0]
     good = ReadBatch.from_segments([segs[i] for i in ok])
     assert_same(oracle.process(good, g.size, mn, mx, mpl, mq, w), runner.process(good, g.size, mn, mx, mpl, mq, w), good)
+
+
+def test_single_rank_rccl_paths(tmp_path, scheme, monkeypatch):
+    """The N > 1 code has to have run before an 8-GPU node shows up: (a) amp_reduce with no communicator is a no-op,
+    (b) one-rank RCCL all-reduce of the bound device table through torch.distributed (backend nccl) leaves the
+    table unchanged and equal to the oracle's, (c) the command line under AMPLIPY_FORCE_DIST=1 (one-rank
+    torchrun rehearsal: range partition, all-reduce, rank 0 writes) gives the same VCF / consensus as the plain run."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from amplipy_amd import amplipy, bamio, lib, parallel
+    g, pr, amps, mn, mx, mpl = scheme
+    b = synth.make_amplicon_batch(g, amps, 30000, seed=21)
+    a = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        e = lib.Engine(g.size)
+        table = torch.zeros(g.size * 7, dtype=torch.int32, device="cuda:0")
+        e.bind_counts(table.data_ptr())
+        e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
+        e.process(b)
+        e.reduce(None, 0)                                   # (a)
+        parallel.allreduce_table(dist, table)               # (b)
+        torch.cuda.synchronize()
+        got = table.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:g.size * 6].reshape(g.size, 6), a.counts)
+        assert int(got[g.size * 6:].sum()) == a.events.size
+        e.close()
+    finally:
+        dist.destroy_process_group()
+    # (c)
+    ref = tmp_path / "ref.fas"; ref.write_text(">SYN_REF test\n" + synth.genome_string(g) + "\n")
+    bed = tmp_path / "p.bed"; bed.write_text("".join("SYN_REF\t%d\t%d\tp%d\n" % (s, e2, i) for i, (s, e2) in enumerate(pr)))
+    hdr = bamio.Header("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:SYN_REF\tLN:%d\n@PG\tID:sim\tPN:sim\n" % g.size, [("SYN_REF", g.size)])
+    from tools.e2e_legs import write_bam
+    inp = str(tmp_path / "in.bam")
+    write_bam(inp, b.slice(0, 8000), g.size)
+    outs = {}
+    for tag, force in (("plain", "0"), ("dist", "1")):
+        monkeypatch.setenv("AMPLIPY_FORCE_DIST", force)
+        monkeypatch.setenv("MASTER_PORT", "29542")
+        v, c = str(tmp_path / (tag + ".vcf")), str(tmp_path / (tag + ".fas"))
+        amplipy.main(["aio", "-i", inp, "-p", str(bed), "-r", str(ref), "-ot", str(tmp_path / (tag + ".bam")), "-ov", v, "-oc", c])
+        outs[tag] = ([l for l in open(v) if not l.startswith("##")], open(c).read())
+    assert outs["plain"] == outs["dist"]
+    assert len(outs["plain"][0]) > 1
