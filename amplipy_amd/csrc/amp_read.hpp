@@ -447,6 +447,176 @@ AMP_HD void trim_quality_apply_simple(TrimState &st, bool is_reverse, int32_t i,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Closed forms for reads with at most ONE insertion or deletion:  [S a][op m1][X k][op m2][S c]
+// with X = I or D (kind 1 / 2; kind 0: no indel, k = m2 = 0).  Every clip of trim_read maps this
+// shape onto itself or onto a shape the closed forms do not cover (an insertion cut in two, an
+// indel left directly behind a soft clip): then `punt` is set and the generic code does the read.
+// Derived rule by rule from primer_clip / quality_clip above; tests/hostsim fuzzes them against
+// trim_read_serial (tests/test_hostsim_golden.py::test_two_segment_closed_forms).
+// ---------------------------------------------------------------------------------------------
+struct Cig2 {
+    uint32_t op;                  // M, = or X: the op of both match segments
+    int32_t a, m1, k, m2, c;
+    int32_t kind;                 // 0 none, 1 insertion, 2 deletion
+    bool punt;
+    AMP_HD int32_t query_len() const { return a + m1 + (kind == 1 ? k : 0) + m2 + c; }
+    AMP_HD int32_t ref_len() const { const int32_t r = m1 + m2 + (kind == 2 ? k : 0); return r ? r : 1; }
+    AMP_HD void canon() {         // no match left: one soft clip
+        if (kind == 0 && m1 == 0) { a += c; c = 0; }
+    }
+    template <class CB>
+    AMP_HD int store(const CB &b) const {
+        int n = 0;
+        if (a > 0) b.set(n++, ((uint32_t)a << 4) | OP_S);
+        if (m1 > 0) b.set(n++, ((uint32_t)m1 << 4) | op);
+        if (kind) { b.set(n++, ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D)); b.set(n++, ((uint32_t)m2 << 4) | op); }
+        if (c > 0) b.set(n++, ((uint32_t)c << 4) | OP_S);
+        return n;
+    }
+    AMP_HD void mirror() { int32_t t = a; a = c; c = t; if (kind) { t = m1; m1 = m2; m2 = t; } }
+};
+
+// the shape of an input CIGAR of n ops (first three words given), or false
+AMP_HD bool cig2_from_words(int n, uint32_t w0, uint32_t w1, uint32_t w2, int32_t lseq, Cig2 &s) {
+    const uint32_t o0 = w0 & 15u;
+    if (!(o0 == OP_M || o0 == OP_EQ || o0 == OP_X) || lseq <= 0) return false;
+    s.op = o0; s.a = 0; s.c = 0; s.punt = false;
+    if (n == 1) { s.m1 = (int32_t)(w0 >> 4); s.kind = 0; s.k = 0; s.m2 = 0; return s.m1 == lseq; }
+    if (n != 3) return false;
+    const uint32_t o1 = w1 & 15u, o2 = w2 & 15u;
+    if (o2 != o0 || !(o1 == OP_I || o1 == OP_D)) return false;
+    s.m1 = (int32_t)(w0 >> 4); s.k = (int32_t)(w1 >> 4); s.m2 = (int32_t)(w2 >> 4); s.kind = o1 == OP_I ? 1 : 2;
+    if (s.m1 <= 0 || s.k <= 0 || s.m2 <= 0) return false;
+    return s.query_len() == lseq;
+}
+
+// get_pos_on_query (A:389-412) on the shape
+AMP_HD int32_t cig2_pos_on_query(const Cig2 &s, int64_t ref_pos, int64_t ref_start) {
+    int64_t q = s.a, cur = ref_start;
+    if (s.m1 > 0) { if (ref_pos <= cur + s.m1) return (int32_t)(q + (ref_pos - cur)); cur += s.m1; q += s.m1; }
+    if (s.kind == 1) q += s.k;
+    else if (s.kind == 2) { if (ref_pos <= cur + s.k) return (int32_t)q; cur += s.k; }
+    if (s.kind && s.m2 > 0) { if (ref_pos <= cur + s.m2) return (int32_t)(q + (ref_pos - cur)); q += s.m2; }
+    return (int32_t)(q + s.c);
+}
+
+// get_pos_on_ref (A:363-386) on the shape
+AMP_HD int32_t cig2_pos_on_ref(const Cig2 &s, int64_t query_pos, int64_t ref_start) {
+    int64_t cur = 0, r = ref_start;
+    if (s.a > 0) { if (query_pos <= cur + s.a) return (int32_t)r; cur += s.a; }
+    if (s.m1 > 0) { if (query_pos <= cur + s.m1) return (int32_t)(r + (query_pos - cur)); cur += s.m1; r += s.m1; }
+    if (s.kind == 1) { if (query_pos <= cur + s.k) return (int32_t)r; cur += s.k; }
+    else if (s.kind == 2) r += s.k;
+    if (s.kind && s.m2 > 0) { if (query_pos <= cur + s.m2) return (int32_t)(r + (query_pos - cur)); cur += s.m2; r += s.m2; }
+    return (int32_t)r;   // (a trailing soft clip returns r either way)
+}
+
+// primer clip of `del` query bases from the front (A:467-510); returns the reference advance
+AMP_HD int32_t cig2_primer_clip(Cig2 &s, int32_t del) {
+    if (del == 0) return 0;
+    if (del < 0) {                // every query-consuming op falls into the "else" arm: all soft clip; a deletion still advances
+        const int32_t adv = s.kind == 2 ? s.k : 0;
+        s.a = s.query_len(); s.m1 = s.m2 = s.k = s.c = 0; s.kind = 0;
+        return adv;
+    }
+    int32_t adv = 0, A = s.a;
+    if (s.a > 0) del = del >= s.a ? del - s.a : 0;                    // a soft clip stays one and eats its share
+    if (s.m1 > 0) {
+        if (del == 0) return 0;                                       // first match op starts the alignment: rest copied
+        if (del < s.m1) { s.a = A + del; s.m1 -= del; return del; }
+        A += s.m1; adv += s.m1; del -= s.m1; s.m1 = 0;
+    }
+    if (s.kind == 1) {
+        if (del > 0 && del < s.k) { s.punt = true; return 0; }         // insertion cut in two
+        A += s.k; del = del >= s.k ? del - s.k : 0;                    // (del == 0: not started yet -> soft clip as well)
+    } else if (s.kind == 2) {
+        adv += s.k;                                                    // dropped, the start jumps over it
+    }
+    int32_t m = s.kind ? s.m2 : 0;
+    if (m > 0 && del > 0) {
+        if (del >= m) { A += m; adv += m; m = 0; }
+        else { A += del; adv += del; m -= del; }
+    }
+    s.a = A; s.m1 = m; s.kind = 0; s.k = 0; s.m2 = 0;
+    s.canon();
+    return adv;
+}
+
+// quality clip of `del` aligned bases from the front (A:597-622)
+AMP_HD void cig2_quality_clip(Cig2 &s, int32_t del) {
+    if (del == 0) return;
+    int32_t A = s.a;
+    if (s.m1 > 0) {
+        if (del < s.m1) { s.a = A + del; s.m1 -= del; return; }
+        A += s.m1; del -= s.m1; s.m1 = 0;
+    }
+    if (s.kind == 1) {
+        if (del < s.k) { s.punt = true; return; }                      // del == 0: the insertion is copied behind the clip; else cut in two
+        A += s.k; del -= s.k;
+    } else if (s.kind == 2) {
+        if (del == 0) { s.punt = true; return; }                       // the deletion is copied behind the clip
+    }
+    int32_t m = s.kind ? s.m2 : 0;
+    if (m > 0 && del > 0) {
+        if (del >= m) { A += m; m = 0; }
+        else { A += del; m -= del; }
+    }
+    s.a = A; s.m1 = m; s.kind = 0; s.k = 0; s.m2 = 0;
+    s.canon();
+}
+
+// Stage 1+2 of trim_read (A:450-558) on the shape, given the two table entries
+AMP_HD void cig2_trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, Cig2 &s,
+                              int32_t left_max_end, int32_t right_min_start) {
+    const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
+    const int32_t at = tlen < 0 ? -tlen : tlen;
+    const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;              // A:452
+    if (!(is_paired && isize_flag && is_reverse) && left_max_end >= 0) {                   // A:460
+        st.flags |= AMP_TRIM_PRIMER_START;
+        const int32_t del = cig2_pos_on_query(s, (int64_t)left_max_end + 1, st.pos);       // A:463
+        st.pos += cig2_primer_clip(s, del);                                                // A:514
+        if (s.punt) return;
+    }
+    if (!(is_paired && isize_flag && !is_reverse) && right_min_start >= 0) {               // A:517
+        st.flags |= AMP_TRIM_PRIMER_END;
+        const int32_t del = lseq - cig2_pos_on_query(s, right_min_start, st.pos);          // A:520
+        s.mirror();
+        (void)cig2_primer_clip(s, del);
+        s.mirror();
+        s.canon();
+    }
+}
+
+// aligned-quality window of the shape (quality_window above): [lo, lo + qlen)
+AMP_HD void cig2_quality_window(const Cig2 &s, int32_t lseq, int32_t &lo, int32_t &qlen) {
+    const bool single = s.m1 == 0 && s.kind == 0;           // one soft clip covering the read: its end is not examined
+    const int32_t qs = s.a, qe = single ? lseq : lseq - s.c;
+    lo = qs > lseq ? lseq : qs;
+    const int32_t hi = qe < lo ? lo : qe;
+    qlen = hi - lo;
+}
+
+// Stage 3 of trim_read given the scan result i (A:589-625, A:651-686)
+AMP_HD void cig2_trim_quality(TrimState &st, bool is_reverse, int32_t i, int32_t qlen, Cig2 &s) {
+    if (is_reverse) {
+        const int32_t del = i;
+        if (cig2_pos_on_ref(s, (int64_t)del + s.a - 1, st.pos) > st.pos) {                 // A:591-594
+            st.flags |= AMP_TRIM_QUALITY;
+            cig2_quality_clip(s, del);                      // reference_start is NOT advanced
+        }
+    } else {
+        const int32_t del = qlen - i;
+        if (del != 0) {                                                                    // A:656
+            st.flags |= AMP_TRIM_QUALITY;
+            s.mirror();
+            cig2_quality_clip(s, del);
+            s.mirror();
+            s.canon();
+        }
+    }
+}
+
 // Whole trim_read (A:426-687) for one read, scanning qualities serially.
 template <class CB>
 AMP_HD void trim_read_serial(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq,
@@ -601,6 +771,39 @@ AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_s
         const uint32_t col = code_to_col(rb.code(q));
         if (col == 0xFFu) return AMP_RS_KEY_BASE;
         sink.add(r, col);
+    }
+    return 0;
+}
+
+// update_base_counts (A:690-753) for the shape, part 1: the effects of its indel.  A deletion counts '-' at each of
+// its positions (A:714-715).  An insertion gives one event per maximal run of good-quality inserted bases
+// (A:730-748): a run that reaches the insertion's end is anchored on the base before
+// it and counted in front of the next match base; a run cut short by a low-quality base is counted at
+// reference_end - 1 and that base is swallowed.  qual(q) -> quality of query base q.
+template <class Sink, class QF>
+AMP_HD int cig2_indels(const KParams &P, const Cig2 &s, int32_t pos, int32_t lseq, const QF &qual, Sink &sink) {
+    const uint32_t G = (uint32_t)P.ref_len;
+    if (s.kind == 2) {
+        for (int32_t j = 0; j < s.k; ++j) {
+            const int32_t r = pos + s.m1 + j;
+            if ((uint32_t)r >= G) return AMP_RS_INDEX_REF;
+            sink.add(r, 5u);
+        }
+    } else if (s.kind == 1) {
+        const int32_t q0 = s.a + s.m1, r2 = pos + s.m1, ref_end = pos + s.ref_len();
+        int32_t j = 0;
+        while (j < s.k) {
+            if ((int32_t)qual(q0 + j) < P.min_quality) { ++j; continue; }                  // A:718
+            const int32_t js = j;
+            while (j < s.k && (int32_t)qual(q0 + j) >= P.min_quality) ++j;
+            int32_t lo, hi, ins_pos;
+            py_slice(q0 + js - 1, q0 + j, lseq, lo, hi);                                   // A:738
+            if (j == s.k) ins_pos = r2;                                                    // A:742
+            else { ins_pos = ref_end; ++j; }                                               // A:739-740; the low base is consumed
+            ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                                   // A:744
+            if ((uint32_t)ins_pos >= G) return AMP_RS_INDEX_REF;
+            sink.event(ins_pos, lo, hi);
+        }
     }
     return 0;
 }

@@ -27,3 +27,12 @@ def process(batch, ref_len, mn, mx, mpl, mq, w, do_trim=True, do_count=True, **k
     L = lib()
     return oracle.process(batch, ref_len, mn, mx, mpl, mq, w, do_trim=do_trim, do_count=do_count,
                           _fn=L.sim_process_range, _free=L.sim_free, **kw)
+
+
+def cig2_fuzz(seed, iters):
+    """(mismatches, punted, compared) of the two-segment closed forms against the generic trim code."""
+    L = lib()
+    L.sim_cig2_fuzz.restype = C.c_long
+    np_, nc = C.c_long(0), C.c_long(0)
+    bad = L.sim_cig2_fuzz(C.c_uint64(seed), C.c_long(iters), C.byref(np_), C.byref(nc))
+    return int(bad), int(np_.value), int(nc.value)

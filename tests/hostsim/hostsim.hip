@@ -2,6 +2,7 @@
 // amplipy_amd/csrc/amp_read.hpp on the CPU so that their logic can be checked against the
 // golden vectors in a container without a GPU.  Never loaded by the amplipy_amd package
 // and not a fallback: the product library has no host execution path.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -61,3 +62,121 @@ extern "C" int sim_process_range(int32_t min_quality, int32_t window, int32_t do
     return 0;
 }
 extern "C" void sim_free(void *p) { free(p); }
+
+
+// ---- fuzz of the two-segment closed forms (Cig2) against the generic trim code ------------------------------
+static uint64_t rng_state;
+static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
+static int32_t rin(int32_t lo, int32_t hi) { return lo + (int32_t)(rnd() % (uint32_t)(hi - lo + 1)); }
+
+// returns the number of mismatches; *n_punt / *n_cmp report how many cases were punted / compared
+extern "C" long sim_cig2_fuzz(uint64_t seed, long iters, long *n_punt, long *n_cmp) {
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 12345;
+    const int32_t G = 2000;
+    std::vector<int32_t> mn(G), mx(G);
+    long bad = 0; *n_punt = 0; *n_cmp = 0;
+    for (long it = 0; it < iters; ++it) {
+        // a few primers, tables like find_overlapping_primers builds them (offset 0..3)
+        const int32_t off = rin(0, 3);
+        for (int p = 0; p < G; ++p) { mn[p] = -1; mx[p] = -1; }
+        int32_t mpl = 0;
+        const int npr = rin(1, 4);
+        for (int j = 0; j < npr; ++j) {
+            const int32_t a = rin(0, 400), b = a + rin(1, 40);
+            mpl = b - a > mpl ? b - a : mpl;
+            for (int32_t p = a - off; p < b + off; ++p)
+                if (p >= 0 && p < G) { mn[p] = mn[p] < 0 || a < mn[p] ? a : mn[p]; mx[p] = b > mx[p] ? b : mx[p]; }
+        }
+        const int32_t window = rin(1, 8), mq = rin(0, 40);
+        KParams P{mq, window, 1, 1, G, mpl, mn.data(), mx.data()};
+        // the read
+        const int kind = rin(0, 2);
+        const int32_t m1 = rin(1, 60), k = kind ? rin(1, 6) : 0, m2 = kind ? rin(1, 60) : 0;
+        const uint32_t op = (rnd() % 8 == 0) ? OP_EQ : OP_M;
+        uint32_t in[3]; int n = 0;
+        in[n++] = ((uint32_t)m1 << 4) | op;
+        if (kind) { in[n++] = ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D); in[n++] = ((uint32_t)m2 << 4) | op; }
+        const int32_t lseq = m1 + (kind == 1 ? k : 0) + m2;
+        const int32_t pos = rin(0, 420);
+        const uint32_t flag = (rnd() & 1u) | ((rnd() & 1u) << 4);
+        const int32_t tlen = (rnd() & 1) ? rin(-600, 600) : 0;
+        std::vector<uint8_t> qual(lseq + 16);
+        const int mode = rin(0, 3);
+        for (int32_t q = 0; q < lseq; ++q) {
+            uint8_t v = (uint8_t)rin(mode == 0 ? 30 : 0, 41);
+            if (mode == 2 && q > lseq - rin(1, 20)) v = 2;
+            if (mode == 3 && q < rin(0, 20)) v = 2;
+            qual[q] = v;
+        }
+        // generic
+        uint32_t a[8] = {0}, b[8] = {0};
+        memcpy(a, in, sizeof(uint32_t) * n);
+        CigBuf<1> cur{a}, tmp{b};
+        TrimState st{pos, n, 0u, 0};
+        trim_read_serial(P, st, flag, tlen, lseq, qual.data(), true, cur, tmp);
+        // closed forms
+        Cig2 s;
+        if (!cig2_from_words(n, in[0], n > 1 ? in[1] : 0u, n > 2 ? in[2] : 0u, lseq, s)) { ++bad; continue; }
+        TrimState t2{pos, n, 0u, 0};
+        const int32_t rs = pos, re1 = pos + s.ref_len() - 1;
+        if ((uint32_t)rs >= (uint32_t)G || (uint32_t)re1 >= (uint32_t)G) t2.err = AMP_RS_INDEX_REF;
+        else {
+            cig2_trim_primers(P, t2, flag, tlen, lseq, s, mx[rs], mn[re1]);
+            if (!s.punt) {
+                int32_t lo, qlen;
+                cig2_quality_window(s, lseq, lo, qlen);
+                const int32_t iq = quality_scan(qual.data() + lo, qlen, window, mq, (flag & 0x10u) != 0);
+                cig2_trim_quality(t2, (flag & 0x10u) != 0, iq, qlen, s);
+            }
+        }
+        if (s.punt) { ++*n_punt; continue; }
+        ++*n_cmp;
+        uint32_t c2[8]; CigBuf<1> cb{c2};
+        const int n2 = t2.err ? 0 : s.store(cb);
+        bool same = st.err == t2.err;
+        if (same && !st.err) {
+            same = st.pos == t2.pos && st.flags == t2.flags && st.n == n2;
+            for (int j = 0; same && j < n2; ++j) same = cur.get(j) == c2[j];
+        }
+        if (same && !st.err) {
+            // counting: generic exact walk against segments + cig2_indels
+            std::vector<uint8_t> seq((lseq + 1) / 2 + 8);
+            for (auto &x : seq) { const uint8_t c[5] = {1, 2, 4, 8, 15}; x = (uint8_t)((c[rnd() % (rnd() % 16 ? 4 : 5)] << 4) | c[rnd() % 4]); }
+            std::vector<uint32_t> c1((size_t)G * AMP_NSYM, 0), cc2((size_t)G * AMP_NSYM, 0);
+            std::vector<amp_ins_event> e1, e2;
+            HostSink s1{c1.data(), &e1, 7u}, s2{cc2.data(), &e2, 7u};
+            const int er1 = count_read_walk(P, cur, st.n, st.pos, lseq, ReadBytes{seq.data(), 0, qual.data()}, true, s1);
+            int er2 = 0;
+            {
+                ReadBytes rb{seq.data(), 0, qual.data()};
+                const int32_t qa[2] = {s.a, s.a + s.m1 + (s.kind == 1 ? s.k : 0)}, ml[2] = {s.m1, s.kind ? s.m2 : 0};
+                const int32_t r0[2] = {t2.pos, t2.pos + s.m1 + (s.kind == 2 ? s.k : 0)};
+                for (int sg = 0; sg < 2 && !er2; ++sg)
+                    for (int32_t j = 0; j < ml[sg]; ++j) {
+                        if ((int32_t)rb.qual(qa[sg] + j) < mq) continue;
+                        const uint32_t col = code_to_col(rb.code(qa[sg] + j));
+                        if (col == 0xFFu || (uint32_t)(r0[sg] + j) >= (uint32_t)G) { er2 = 1; break; }
+                        s2.add(r0[sg] + j, col);
+                    }
+                if (!er2) er2 = cig2_indels(P, s, t2.pos, lseq, [&](int32_t q) { return (uint32_t)qual[q]; }, s2);
+            }
+            if ((er1 != 0) != (er2 != 0)) same = false;
+            else if (!er1) {
+                same = c1 == cc2 && e1.size() == e2.size();
+                for (size_t j = 0; same && j < e1.size(); ++j)
+                    same = e1[j].ref_pos == e2[j].ref_pos && e1[j].q_from == e2[j].q_from && e1[j].q_to == e2[j].q_to;
+            }
+        }
+        if (!same) {
+            if (bad < 8 && getenv("CIG2_DEBUG")) {
+                fprintf(stderr, "MISMATCH kind %d m1 %d k %d m2 %d pos %d flag %u tlen %d w %d mq %d | generic err %d pos %d flags %u n %d:", kind, m1, k, m2, pos, flag, tlen, window, mq, st.err, st.pos, st.flags, st.n);
+                for (int j = 0; j < st.n; ++j) fprintf(stderr, " %u%c", cur.get(j) >> 4, "MIDNSHP=X"[cur.get(j) & 15]);
+                fprintf(stderr, " | cig2 err %d pos %d flags %u n %d:", t2.err, t2.pos, t2.flags, n2);
+                for (int j = 0; j < n2; ++j) fprintf(stderr, " %u%c", c2[j] >> 4, "MIDNSHP=X"[c2[j] & 15]);
+                fprintf(stderr, " L %d R %d\n", mx[rs], mn[re1 < G && re1 >= 0 ? re1 : 0]);
+            }
+            ++bad;
+        }
+    }
+    return bad;
+}

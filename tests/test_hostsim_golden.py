@@ -105,3 +105,14 @@ def test_closed_form_trims_of_single_op_reads(seed, mq, w, off):
     assert np.array_equal(a.trim.new_ncig, d.trim.new_ncig)
     assert np.array_equal(a.trim.compact_cigars(), d.trim.compact_cigars())
     assert len(set(a.trim.trim_flags.tolist())) >= 4          # the cases are really visited
+
+
+def test_two_segment_closed_forms():
+    """The closed forms for reads with at most one insertion / deletion (Cig2 in amp_read.hpp: primer clips, quality
+    clip, counted segments, deletion counts, insertion events) against the generic exact code on random reads,
+    primer tables, windows and qualities.  Cases the closed forms do not cover must be flagged (punt), never wrong."""
+    from tests import hostsim
+    for seed in (11, 12, 13):
+        bad, punted, compared = hostsim.cig2_fuzz(seed, 200000)
+        assert bad == 0, (seed, bad)
+        assert compared > 190000 and punted < 5000
