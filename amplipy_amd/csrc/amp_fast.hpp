@@ -44,16 +44,14 @@ constexpr int F_PW = 256;             // reference positions covered by a wave's
 constexpr int F_REP = 8;              // replicas of the packed window
 constexpr int F_REPW = F_PW + 1;      // words per replica: one word of skew, so that replica r is shifted by r banks
 constexpr int F_BW = 512;             // reference positions covered by the block's 32-bit window
-constexpr int F_NPL = 4;              // its planes: A C G T (N and '-' never take the fast path)
+constexpr int F_NPL = 4;              // its base planes: A C G T (a counted N goes straight to the table)
+constexpr int F_BPL = 6;              // ... followed by '-' (deletions) and the insertion-event tally
+constexpr int F_MAXINS = 8;           // longest insertion / deletion of a read the fast path takes
+constexpr int F_MAXDEL = 16;
+constexpr uint32_t F_EVGRAN = 64;     // event-list slots a wave reserves at a time
 constexpr int F_STAGE = 10240;        // bytes of a wave's staging buffer = the longest run of quality bytes a tile may span
 constexpr int F_PAD = 16;             // bytes in front of the staged run (rows that start 8 bases early)
 constexpr int F_FLUSH = 15;           // tiles between two folds of a packed window (16 increments per counter and tile at most)
-
-struct FastLds {
-    uint4 stage[F_WAVES][(F_PAD + F_STAGE + 16) / 16];   // per wave: the tile's quality bytes, then its packed bases
-    uint32_t pwin[F_WAVES][F_REP * F_REPW];              // per wave: packed counters, byte c of a word = base c (A C G T)
-    uint32_t bwin[F_NPL * F_BW];                         // the block's window, 32-bit counters
-};
 
 struct FastGrid { int64_t grid, rpb; };
 static inline FastGrid fast_grid(int64_t n_reads, int n_cu) {
@@ -118,20 +116,131 @@ __device__ __forceinline__ uint32_t shl_byte(uint32_t sh, uint32_t val) {
     return r;
 }
 
+// LDS adds of the counting phase, written as inline assembly ON PURPOSE.  While a tile is counted the next tile's
+// quality bytes are on their way into the staging buffer by LDS-DMA, and the compiler answers every LDS access it can
+// see with s_waitcnt vmcnt(0) as long as such a load is in flight (it cannot prove that the counters and the staging
+// buffer are different memory): the counting phase would wait for the bytes it is meant to overlap with.  An
+// instruction inside an asm statement is not tracked.  LDS operations of a wave complete in order, so the waits the
+// compiler places for its own LDS reads stay sufficient with these adds in between.
+__device__ __forceinline__ void lds_add_nt(lds_u32 *p, uint32_t v) {
+    asm volatile("ds_add_u32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+// counter word at wb + 4 * B  +=  (byte J of val) << (byte J of sh): the SDWA shift and the add of one base
+template <int J, int B>
+__device__ __forceinline__ void add_base(uint32_t wb, uint32_t sh, uint32_t val) {
+    uint32_t t;
+    if (J == 0) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory");
+    if (J == 1) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory");
+    if (J == 2) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory");
+    if (J == 3) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory");
+}
+
 // 16 failing-window bits of one piece: bit b set <=> the W-byte window starting at byte b of q (continued in nx) sums to < thr
 template <int W>
 __device__ __forceinline__ uint32_t piece_fail_bits(const uint4 &q, const uint2 &nx, uint32_t thr) {
+    if (W == 4) {
+        // v_qsad_pk_u16_u8 gives four sliding 4-byte sums per instruction and ADDS its third operand to each: with
+        // 65536 - thr there, bit 15 of a sum is "sum < thr" (thr <= 2048).  The 16 sign bits are gathered by a packed
+        // shift (bit 15 -> bit 0 of each half) and v_dot4_u32_u8 with power-of-two weights.
+        typedef unsigned short amp_u16x2 __attribute__((ext_vector_type(2)));
+        const uint64_t nthr = (uint64_t)((0x10000u - thr) & 0xFFFFu) * 0x0001000100010001ull;
+        const uint64_t s0 = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)q.x | ((uint64_t)q.y << 32), 0u, nthr);
+        const uint64_t s1 = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)q.y | ((uint64_t)q.z << 32), 0u, nthr);
+        const uint64_t s2 = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)q.z | ((uint64_t)q.w << 32), 0u, nthr);
+        const uint64_t s3 = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)q.w | ((uint64_t)nx.x << 32), 0u, nthr);
+        const uint32_t d[8] = {(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32),
+                               (uint32_t)s2, (uint32_t)(s2 >> 32), (uint32_t)s3, (uint32_t)(s3 >> 32)};
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = (1u << (2 * j)) | (2u << (2 * j + 16));          // weights of the two windows of a dword
+            const uint32_t a = __builtin_bit_cast(uint32_t, __builtin_bit_cast(amp_u16x2, d[j]) >> (unsigned short)15);
+            const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_bit_cast(amp_u16x2, d[j + 4]) >> (unsigned short)15);
+            lo = __builtin_amdgcn_udot4(a, w, lo, false);
+            hi = __builtin_amdgcn_udot4(b, w, hi, false);
+        }
+        return lo | (hi << 8);
+    }
     return window_fail_bits16<W>(make_uint2(q.x, q.y), make_uint2(q.z, q.w), thr) |
            (window_fail_bits16<W>(make_uint2(q.z, q.w), nx, thr) << 8);
 }
 
-// in-kernel phase stamps (development builds only; the numbers are shares, not durations)
-#ifdef AMP_DEV
-#define F_STAMP_DECL unsigned long long f_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_prev = __builtin_amdgcn_s_memtime()
+// zero when every one of the 8 base codes packed in x is one of A C G T (exactly one bit per nibble)
+__device__ __forceinline__ uint32_t acgt_defect8(uint32_t x) {
+    const uint32_t m = 0x11111111u;
+    return ((x & m) + ((x >> 1) & m) + ((x >> 2) & m) + ((x >> 3) & m)) ^ m;
+}
+
+// per byte: 8 * plane number of an A C G T code (a byte permute: 1 2 4 8 -> selector 1 2 4 0 -> 0 8 16 24)
+__device__ __forceinline__ uint32_t shift_bytes_acgt(uint32_t cb) {
+    return __builtin_amdgcn_perm(0x00000010u, 0x00080018u, cb & 0x07070707u);
+}
+
+// One piece (16 bases in registers: qualities q, packed codes sq) against the counted query range [qa_, qb_)
+// (piece coordinates, the piece starts at j0): every base that is inside the range and good enough adds 1 to
+// its counter byte.  dbase_ = window offset of piece coordinate 0, wrep = LDS address of
+// the lane's replica of the wave's packed window, pw_lim = its usable width.  Returns true when the piece has to be redone
+// by the careful loop (a counted code outside A C G T, or the piece leaves the packed window).
+__device__ __forceinline__ bool fast_count_piece(const uint4 &q, const uint2 &sq, int32_t j0, int32_t qa_, int32_t qb_, int32_t dbase_,
+                                             uint32_t mqb, uint32_t pw_lim, uint32_t wrep) {
+    // Straight-line code on purpose: the slots are rotated per lane, so some lane of the wave has work in every
+    // slot and a branch around an empty piece would never be taken by the whole wave; what a divergent branch costs
+    // here is its v_cmp -> s_and_saveexec -> s_cbranch chain, which two waves per SIMD cannot hide.  A lane without
+    // counted bases adds zeros.
+    int32_t klo = qa_ - j0, khi = qb_ - j0;
+    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
+    const int32_t d0 = dbase_ + j0;                                 // window offset of the piece's base 0
+    const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);  // empty when khi <= klo
+    // per base (byte): 1 = counted (quality and range), code, shift count of its counter byte
+    uint32_t f[4], cb[4], sh[4];
+    f[0] = (ok_bits4(q.x, mqb) >> 7) & nibble_to_bytes(rng, 0);
+    f[1] = (ok_bits4(q.y, mqb) >> 7) & nibble_to_bytes(rng, 1);
+    f[2] = (ok_bits4(q.z, mqb) >> 7) & nibble_to_bytes(rng, 2);
+    f[3] = (ok_bits4(q.w, mqb) >> 7) & nibble_to_bytes(rng, 3);
+    spread_codes(sq, cb);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sh[d] = shift_bytes_acgt(cb[d]);
+    const uint32_t counted_any = f[0] | f[1] | f[2] | f[3];
+    const bool inwin = pw_lim >= 16u && (uint32_t)d0 <= pw_lim - 16u;
+    bool redo = counted_any != 0u && !inwin;                        // the piece leaves the packed window
+    if (acgt_defect8(sq.x) | acgt_defect8(sq.y)) {                  // rare: some code of the piece is not A C G T
+        uint32_t bad = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bad |= (not_acgt(cb[d]) >> 7) & f[d];
+        redo = redo || bad != 0u;                                   // ... and it is a counted one (a counted N takes the careful loop too)
+    }
+    const uint32_t keep = redo ? 0u : 0xFFFFFFFFu;
+    const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u : 0u);
+#if defined(AMP_DEV) && defined(AMP_ABL)
+    if (AMP_ABL & 1) { asm volatile("" : : "v"(wb), "v"(sh[0] + sh[1] + sh[2] + sh[3]), "v"((f[0] + f[1] + f[2] + f[3]) & keep)); return redo; }   // ablation: no adds
+#endif
+    const uint32_t f0 = f[0] & keep, f1 = f[1] & keep, f2 = f[2] & keep, f3 = f[3] & keep;
+    add_base<0, 0>(wb, sh[0], f0);   add_base<1, 1>(wb, sh[0], f0);   add_base<2, 2>(wb, sh[0], f0);   add_base<3, 3>(wb, sh[0], f0);
+    add_base<0, 4>(wb, sh[1], f1);   add_base<1, 5>(wb, sh[1], f1);   add_base<2, 6>(wb, sh[1], f1);   add_base<3, 7>(wb, sh[1], f1);
+    add_base<0, 8>(wb, sh[2], f2);   add_base<1, 9>(wb, sh[2], f2);   add_base<2, 10>(wb, sh[2], f2);  add_base<3, 11>(wb, sh[2], f2);
+    add_base<0, 12>(wb, sh[3], f3);  add_base<1, 13>(wb, sh[3], f3);  add_base<2, 14>(wb, sh[3], f3);  add_base<3, 15>(wb, sh[3], f3);
+    return redo;
+}
+
+// in-kernel phase stamps (development builds only; the numbers are shares, not durations); AMP_ABL = ablation
+// builds (parts of the kernel switched off to time the rest: results are wrong on purpose), without stamps
+#if defined(AMP_DEV) && !defined(AMP_ABL)
+#define F_DBG_PARAM , uint32_t *f_dbg
+#define F_GLOB ++f_glob
+#define F_EPI(k) do { __builtin_amdgcn_s_waitcnt(0); f_ep[k] = wall_clock64(); } while (0)
+#define F_DBG_ARG(x) , (x)
+#define F_STAMP_DECL unsigned long long f_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_prev = __builtin_amdgcn_s_memtime(); const unsigned long long f_k0 = f_prev, f_w0 = wall_clock64(); unsigned long long f_ep[3] = {0, 0, 0}; uint32_t f_glob = 0
 #define F_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define F_STAMP_VM(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0070); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define F_STAMP_OUT do { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f_t[k]); } while (0)
+#define F_STAMP_OUT do { f_t[0] = __builtin_amdgcn_s_memtime() - f_k0; const unsigned long long f_w1 = wall_clock64(); f_t[7] = f_w1 - f_w0; if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f_t[k]); \
+    atomicMax(&ctr[4], f_t[7]); atomicMax(&ctr[5], ~f_t[7]); atomicMax(&ctr[6], ~f_w0); atomicMax(&ctr[7], f_w1); \
+    if (f_dbg && wave == 0) { uint32_t *f_o = f_dbg + blockIdx.x * 8; f_o[0] = (uint32_t)f_t[7]; f_o[1] = (uint32_t)f_w0; for (int k = 1; k < 7; ++k) f_o[1 + k] = (uint32_t)(f_t[k] >> 4); } \
+    if (f_dbg) { uint32_t *f_o = f_dbg + 2048 + (blockIdx.x * F_WAVES + wave) * 6; for (int k = 1; k < 7; ++k) f_o[k - 1] = (uint32_t)(f_t[k] >> 4); } } } while (0)
 #else
+#define F_DBG_PARAM
+#define F_DBG_ARG(x)
+#define F_GLOB
+#define F_EPI(k)
 #define F_STAMP_DECL
 #define F_STAMP(k)
 #define F_STAMP_VM(k)
@@ -140,16 +249,23 @@ __device__ __forceinline__ uint32_t piece_fail_bits(const uint4 &q, const uint2 
 
 template <int W>
 __global__ void __launch_bounds__(F_WAVES * 64, 2)
-k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long long *ctr, uint32_t *glist, uint32_t *gcnt,
-       int reads_per_block) {
-    __shared__ FastLds L;
+k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
+       int reads_per_block F_DBG_PARAM) {
+    // THREE separate LDS objects, not one struct: the compiler orders every LDS access behind LDS-DMA loads in flight
+    // (s_waitcnt vmcnt) unless alias scopes tell it that the access cannot touch the DMA's destination, and it only
+    // builds those scopes per LDS variable.  With one struct every counter add waited for the next tile's bytes.
+    __shared__ uint4 s_stage[F_WAVES][(F_PAD + F_STAGE + 16) / 16];   // per wave: the tile's quality bytes, then its packed bases
+    __shared__ uint32_t s_pwin[F_WAVES][F_REP * F_REPW];              // per wave: packed counters, byte c of a word = base c (A C G T)
+    __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
+    unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    F_STAMP_DECL;
     const int64_t n = rd.n_reads;
     const int64_t rb = (int64_t)blockIdx.x * reads_per_block;
     const int64_t re = rb + reads_per_block < n ? rb + reads_per_block : n;
-    lds_u32 *const bwin = (lds_u32 *)L.bwin;
-    lds_u32 *const pwin = (lds_u32 *)L.pwin[wave];
-    for (int i = tid; i < F_NPL * F_BW; i += F_WAVES * 64) bwin[i] = 0;
+    lds_u32 *const bwin = (lds_u32 *)s_bwin;
+    lds_u32 *const pwin = (lds_u32 *)s_pwin[wave];
+    for (int i = tid; i < F_BPL * F_BW; i += F_WAVES * 64) bwin[i] = 0;
     for (int i = lane; i < F_REP * F_REPW; i += 64) pwin[i] = 0;
     // the block's window: anchored 16 positions left of its first read (sorted input: nothing of this block starts
     // left of that read)
@@ -171,10 +287,14 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
     const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
     lds_u8 *const wrep = (lds_u8 *)pwin + rep * (uint32_t)(F_REPW * 4);
-    lds_u8 *const stage = (lds_u8 *)L.stage[wave] + F_PAD;          // the run starts here
+    lds_u8 *const stage = (lds_u8 *)s_stage[wave] + F_PAD;          // the run starts here
     int32_t pw_base = 0;                                            // anchor of the wave's packed window
     int pw_tiles = F_FLUSH;                                         // tiles added since the last fold (forces an anchor for the first tile)
-    F_STAMP_DECL;
+    // the wave's granule of the event list (see the insertion events below)
+    const unsigned ev_shard = blockIdx.x & (EV_SHARDS - 1);
+    amp_ins_event *const ev_list = eb.ev + (size_t)ev_shard * (size_t)eb.cap;
+    unsigned long long ev_base = 0;
+    uint32_t ev_left = 0;
 
     // folds the wave's packed window into the block's 32-bit window (or the global table) and clears it
     auto fold = [&]() {
@@ -196,17 +316,27 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
                 for (int c = 0; c < 4; ++c) {
                     if (!c4[c]) continue;
                     if (d < (uint32_t)F_BW) lds_add(bwin + c * F_BW + d, c4[c]);
-                    else if ((uint32_t)p < G) atomicAdd(&counts[(size_t)p * AMP_NSYM + c], c4[c]);
+                    else if ((uint32_t)p < G) { atomicAdd(&counts[(size_t)p * AMP_NSYM + c], c4[c]); F_GLOB; }
                 }
             }
         }
         wave_sync();
     };
+    // the slots a wave reserved on the event list and did not use are marked (ref_pos = -1: dropped at read-out)
+    auto pad_events = [&]() {
+        if ((uint32_t)lane < ev_left && (long long)(ev_base + (unsigned)lane) < eb.cap) ev_list[ev_base + (unsigned)lane] = amp_ins_event{-1, 0u, 0, 0};
+    };
 
-    // ---- software pipeline: while tile t is computed from registers, the bytes of tile t + 1 are on their way --
+    // ---- software pipeline: while tile t is computed from registers, the bytes of tile t + 1 are on their way and the
+    // header of tile t + 2 is being read.  Loads of one tile form a chain header -> CIGAR words -> primer-table entries;
+    // each link is issued one stage after the link before it has been waited for, so nothing in the loop waits for a
+    // load it has just issued ------------------------------------------------------------------------------------------
     struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };
-    struct Geo { uint32_t np, phi, row, Tq; int ntake; bool solo, taken, fastq, in_ref; };
-    struct L2 { uint32_t w0; int32_t tabL, tabR; uint2 raws[F_STAGE / 1024]; };
+    struct Cg { uint32_t w0, w1, w2; };
+    struct Geo { uint32_t np, phi, row, Tq; int ntake; bool solo, taken, fastq; };
+    struct Tabs { int32_t L, R; };
+    struct Bytes { uint2 raws[F_STAGE / 1024]; };
+    struct Shape { Cig2 s; bool ok; int32_t refspan; };
     auto load_hdr = [&](int64_t t0) {
         Hdr h{0, 0, 0u, 0u, 0u, 0u, 0u};
         const int64_t i = t0 + lane;
@@ -215,6 +345,14 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             h.c0 = rd.cig_off32[i]; h.c1 = rd.cig_off32[i + 1]; h.o8 = rd.seq_off8[i];
         }
         return h;
+    };
+    // the first three CIGAR words (lanes past the wave's reads have c1 == c0)
+    auto load_cig = [&](const Hdr &h) {
+        Cg c{0u, 0u, 0u};
+        const uint32_t nops = h.c1 - h.c0;
+        if (nops >= 1u) c.w0 = rd.cig[h.c0];
+        if (nops == 3u) { c.w1 = rd.cig[h.c0 + 1]; c.w2 = rd.cig[h.c0 + 2]; }
+        return c;
     };
     // the tile: the leading reads whose bytes form one run of at most F_STAGE quality bytes
     auto geometry = [&](const Hdr &h, int64_t t0, uint32_t &m0) {
@@ -237,17 +375,31 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
         g.taken = lane < g.ntake && !g.solo;
         g.Tq = g.solo ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)(g.row + 8u * nch), g.ntake - 1);   // bytes of the run (scalar)
         g.fastq = g.taken && shortq;
-        g.in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + (int32_t)h.lseq - 1) < G;          // A:450-451
         return g;
     };
-    // second level of loads: first CIGAR word, the two primer-table entries of A:450-451 (for a simple read they
-    // depend on the header only), the tile's quality bytes by LDS-DMA (lane l moves bytes [1024 s + 16 l, + 16) of
-    // the run to the same offset of the staging buffer) and its packed bases (8 bytes per lane and load)
-    auto issue_l2 = [&](const Hdr &h, const Geo &g, uint32_t m0) {
-        L2 x;
-        x.w0 = 0; x.tabL = -1; x.tabR = -1;
-        if (g.fastq && h.c1 > h.c0) x.w0 = rd.cig[h.c0];
-        if (g.fastq && P.do_trim && g.in_ref) { x.tabL = P.max_end[h.pos]; x.tabR = P.min_start[h.pos + (int32_t)h.lseq - 1]; }
+    // The shape of a read the fast path takes: one match op ("150M"), or two around ONE insertion / deletion
+    // ("70M2I78M", "70M3D80M"); refspan = its reference length (A:451 looks the right table up at its last position)
+    auto shape_of = [&](const Hdr &h, const Cg &c, bool fastq) {
+        Shape r;
+        r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+        const int nops = (int)(h.c1 - h.c0);
+        r.ok = fastq && (nops == 1 || nops == 3) && cig2_from_words(nops, c.w0, c.w1, c.w2, (int32_t)h.lseq, r.s);
+        if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
+        if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+        r.refspan = r.s.kind ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : (int32_t)h.lseq;
+        return r;
+    };
+    // the two primer-table entries of A:450-451
+    auto load_tabs = [&](const Hdr &h, const Shape &sh) {
+        Tabs t{-1, -1};
+        const bool in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + sh.refspan - 1) < G;
+        if (sh.ok && P.do_trim && in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
+        return t;
+    };
+    // the tile's quality bytes by LDS-DMA (lane l moves bytes [1024 s + 16 l, + 16) of the run to the same offset of
+    // the staging buffer) and its packed bases (8 bytes per lane and load)
+    auto issue_bytes = [&](const Geo &g, uint32_t m0) {
+        Bytes x;
         const uint8_t *qrun = rd.qual + (int64_t)m0 * 8;
         const uint8_t *srun = rd.seq + (int64_t)m0 * 4;
         // lanes past the run re-read its end
@@ -271,15 +423,20 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
     // Results of a tile are STORED ONE TILE LATER, right behind the wait at the top of the loop: stores and loads
     // retire through one in-order counter, so a store issued at the end of a tile would make that wait
     // last until the store has reached memory.
-    struct Pend { int64_t i; uint32_t slot_lo; int32_t pos, reflen; uint32_t ncig, cw0, cw1, cw2, status, flags, entry; bool simple, has; };
-    Pend pend{0, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, false, false};
+    struct Pend { int64_t i; uint32_t slot_lo; int32_t pos, reflen; uint32_t ncig, cw0, cw1, cw2, cw3, cw4, status, flags, entry; bool stored, has; };
+    Pend pend{0, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, false, false};
     uint32_t gwave = 0;                                             // entries of this wave's segment of the general list
     auto store_pending = [&](const Pend &r) {
-        if (r.simple) {
+#if defined(AMP_DEV) && defined(AMP_ABL)
+        if (AMP_ABL & 8) return;
+#endif
+        if (r.stored) {
             uint32_t *home = out.new_cig + ((size_t)r.slot_lo + 3 * (size_t)r.i);
             if (r.ncig > 0u) home[0] = r.cw0;
             if (r.ncig > 1u) home[1] = r.cw1;
             if (r.ncig > 2u) home[2] = r.cw2;
+            if (r.ncig > 3u) home[3] = r.cw3;
+            if (r.ncig > 4u) home[4] = r.cw4;
             if (out.new_pos) out.new_pos[r.i] = r.pos;
             if (out.new_ncig) out.new_ncig[r.i] = r.ncig;
             if (out.ref_len) out.ref_len[r.i] = r.reflen;
@@ -293,24 +450,45 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
         gwave += (uint32_t)__popcll(m);
     };
 
-    int64_t i0 = wbeg, i1 = wbeg;
-    Hdr hA = load_hdr(i0), hB{0, 0, 0u, 0u, 0u, 0u, 0u};
-    uint32_t m0A = 0, m0B = 0;
-    Geo gA = geometry(hA, i0, m0A), gB = gA;
-    L2 xA{}, xB{};
-    xA = issue_l2(hA, gA, m0A);
-    i1 = i0 + gA.ntake;
-    hB = load_hdr(i1);
-    while (i0 < wend) {
+    uint32_t pw_lim = 0;
+    auto count_piece = [&](const uint4 &q, const uint2 &sq, int32_t j0, int32_t qa_, int32_t qb_, int32_t dbase_) -> bool {
+        return fast_count_piece(q, sq, j0, qa_, qb_, dbase_, mqb, pw_lim, (uint32_t)(uintptr_t)wrep);
+    };
+
+    // ---- prologue: header and bytes of the first tile, header of the second ----------------------------------------
+    // Loop-carried state: hN/cN/gN/xN/m0N belong to the NEXT tile (its bytes are in flight), hN2 is the header of the one
+    // after it.  They are renamed to "this tile" at the top of the loop, behind the wait, so that no register with a
+    // load in flight is touched between the issue of a tile's loads and that wait (the compiler answers every such
+    // touch with s_waitcnt vmcnt(0), which would wait for the bytes just requested).
+    int64_t i0 = wbeg, i1 = wbeg, i2 = wbeg;
+    int tile_no = 0; (void)tile_no;
+    Hdr hN = load_hdr(i1), hN2{0, 0, 0u, 0u, 0u, 0u, 0u};
+    Cg cN = load_cig(hN);
+    uint32_t m0N = 0;
+    Geo gN = geometry(hN, i1, m0N);
+    Bytes xN = issue_bytes(gN, m0N);
+    i2 = i1 + gN.ntake;
+    hN2 = load_hdr(i2);
+    while (i1 < wend) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the DMA of this tile's qualities has landed, its other loads too
+        F_STAMP(1);
+#if defined(AMP_DEV) && defined(AMP_ABL)
+        if (AMP_ABL & 32) { if (((tile_no++) + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
+        const Hdr h = hN;
+        const Cg cA = cN;
+        const Geo g = gN;
+        const Bytes xA = xN;
+        hN = hN2;
+        i0 = i1; i1 = i2;
         const int64_t i = i0 + lane;
-        const Hdr h = hA;
-        const Geo g = gA;
         const int32_t pos = h.pos, tlen = h.tlen;
-        const uint32_t lseq = h.lseq, flag = h.flag, c0 = h.c0, c1 = h.c1, o8 = h.o8;
+        const uint32_t lseq = h.lseq, flag = h.flag, c0 = h.c0, o8 = h.o8;
         const uint32_t np = g.np, phi = g.phi;
-        const bool solo = g.solo, taken = g.taken, fastq = g.fastq, in_ref = g.in_ref;
-        const uint32_t w0 = xA.w0;
-        const int32_t tabL = xA.tabL, tabR = xA.tabR;
+        const bool solo = g.solo, taken = g.taken, fastq = g.fastq;
+        // the primer-table entries of this tile (they hang on its CIGAR words): a short wait behind the row reads below
+        const Shape shp = shape_of(h, cA, fastq);
+        const Tabs tA = load_tabs(h, shp);
         // ---- the wave's packed window: fold and re-anchor when the tile has moved on, or before a byte could overflow
         {
             const int32_t first_pos = __builtin_amdgcn_readfirstlane(pos);
@@ -321,17 +499,16 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             }
             ++pw_tiles;
         }
-        const uint32_t pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+        pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
         // ---- rows: slot k of the lane holds piece (k + rot) mod np of its read (slots >= np: a copy of the last
         // piece and an index past the read, which every range test below excludes) -------------------------------
         const uint32_t rot = (uint32_t)lane % np;
         const uint8_t *qrow = rd.qual + (int64_t)o8 * 8;
         const uint8_t *srow = rd.seq + (int64_t)o8 * 4;
         const int32_t lrow = fastq ? (int32_t)g.row - (int32_t)phi : 0;        // >= -8: the pad in front of the run
+        const lds_u8 *const lq = stage + (fastq ? (int32_t)g.row : 0);         // the read's qualities in the staging buffer
         uint4 q16[F_NP];
         uint2 s8[F_NP];
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the DMA of this tile's qualities has landed, its other loads too
-        F_STAMP(1);
         wave_sync();
 #pragma unroll
         for (int k = 0; k < F_NP; ++k) {
@@ -342,6 +519,33 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8);
             q16[k] = make_uint4(a.x, a.y, b.x, b.y);
         }
+        // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------
+        Cig2 s = shp.s;
+        const bool shaped = shp.ok;
+        const bool in_ref = (uint32_t)pos < G && (uint32_t)(pos + shp.refspan - 1) < G;          // A:450-451
+        const bool rev = (flag & 0x10u) != 0;
+        // query index of the first inserted base / of the base behind the deletion, and of the second match segment:
+        // no clip moves them while the indel survives
+        const int32_t q_ins = s.kind ? s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
+        TrimState ts{pos, 1, 0u, 0};
+        if (shaped && P.do_trim) {
+            if (!in_ref) ts.err = AMP_RS_INDEX_REF;
+            else cig2_trim_primers(P, ts, flag, tlen, (int32_t)lseq, s, tA.L, tA.R);
+        }
+        const bool scan = shaped && P.do_trim && !ts.err && !s.punt;
+        // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
+        int32_t lo = 0, qlen = 0;
+        if (scan) { cig2_quality_window(s, (int32_t)lseq, lo, qlen); lo += (int32_t)phi; }
+        const int32_t hi = lo + qlen;
+        // Bytes the slots cannot give (they are rotated per lane), read from the staged qualities while they are still there:
+        // the 3' end's shrinking windows (A:575-576, A:637-638) need at most W-1 bytes; reads with an indel need the
+        // qualities around the insertion and GROUP B = the 16 bases from the 8-aligned start of the second segment, for
+        // the piece that holds bases of both segments (its second part is counted from this copy)
+        const int32_t first = !scan ? 0 : ((rev || qlen < W) ? lo : lo + qlen - W + 1) - (int32_t)phi;      // query index
+        const int32_t tab = first & ~7, g_ins = q_ins & ~7, g_b = q_seg2 & ~7;
+        const amp_u32x2 tw0 = *(const lds_u32x2 *)(lq + tab), tw1 = *(const lds_u32x2 *)(lq + tab + 8);
+        const amp_u32x2 iq0 = *(const lds_u32x2 *)(lq + g_ins), iq1 = *(const lds_u32x2 *)(lq + g_ins + 8);
+        const amp_u32x2 bq0 = *(const lds_u32x2 *)(lq + g_b), bq1 = *(const lds_u32x2 *)(lq + g_b + 8);
         wave_sync();
 #pragma unroll
         for (int sl = 0; sl < F_STAGE / 1024; ++sl) *(lds_u32x2 *)(stage + sl * 512 + lane * 8) = amp_u32x2{xA.raws[sl].x, xA.raws[sl].y};
@@ -354,37 +558,33 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             const lds_u8 *src = stage + (lrow >> 1) + (int32_t)(p * 8u);
             s8[k] = make_uint2(*(const lds_u32 *)src, *(const lds_u32 *)(src + 4));
         }
+        const lds_u8 *const lsq = stage + (fastq ? (int32_t)(g.row >> 1) : 0) + (g_b >> 1);
+        const uint2 bsq = make_uint2(*(const lds_u32 *)lsq, *(const lds_u32 *)(lsq + 4));
         wave_sync();                                 // every lane has its rows: the staging buffer may be overwritten
         store_pending(pend);                         // the previous tile's results
-        // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------
-        const bool simple = fastq && c1 - c0 == 1u && is_simple_cigar(1, w0, (int32_t)lseq);
-        const bool rev = (flag & 0x10u) != 0;
-        TrimState ts{pos, 1, 0u, 0};
-        SimpleCig sc{w0 & 15u, 0, (int32_t)lseq, 0};
-        if (simple && P.do_trim) {
-            if (!in_ref) ts.err = AMP_RS_INDEX_REF;
-            else trim_primers_simple_tab(P, ts, flag, tlen, (int32_t)lseq, sc, tabL, tabR);
+        // ---- next tile: its CIGAR words and bytes start moving now (its header arrived with this tile's bytes), and the
+        // header of the tile behind it.  Nothing below touches them before the wait at the top of the loop.  No branch
+        // around the loads of the bytes (behind the wave's last tile they fetch the first bytes of the batch) ---------
+#if defined(AMP_DEV) && defined(AMP_ABL)
+        if (!(AMP_ABL & 64) || i1 < wend) {
+#else
+        {
+#endif
+        cN = load_cig(hN);
+        gN = geometry(hN, i1, m0N);
+        xN = issue_bytes(gN, m0N);
+        i2 = i1 + gN.ntake;
+        hN2 = load_hdr(i2);
         }
-        const bool scan = simple && P.do_trim && !ts.err;
-        // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
-        const int32_t lo = !scan ? 0 : (sc.m > 0 ? sc.a : (int32_t)lseq) + (int32_t)phi, qlen = scan ? sc.m : 0, hi = lo + qlen;
-        // the 3' end's shrinking windows (A:575-576, A:637-638) need at most W-1 bytes; loaded by every lane (from
-        // the start of its read when there is nothing to scan): a load under a branch is waited for at its end
-        const int32_t first = !scan ? 0 : ((rev || qlen < W) ? lo : lo + qlen - W + 1) - (int32_t)phi;      // query index
-        const int32_t tab = first & ~7;
-        const uint2 tw0 = *(const uint2 *)(qrow + tab), tw1 = *(const uint2 *)(qrow + tab + 8);
-        // ---- next tile: its bytes start moving now, its header was loaded during the previous tile.  No branch
-        // around these loads (behind the wave's last tile they fetch the first bytes of the batch): a branch would
-        // make the compiler wait for everything in flight at its end ------------------------------------------------
-        gB = geometry(hB, i1, m0B);
-        xB = issue_l2(hB, gB, m0B);
-        const int64_t i2 = i1 + gB.ntake;
-        const Hdr hC = load_hdr(i2);
         F_STAMP(2);          // staged, rows in registers, primer clips, next tile issued
 
         // ---- sliding-window scan: first failing window start (forward) / last failing window end (reverse) --
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
+#if defined(AMP_DEV) && defined(AMP_ABL)
+        if (P.do_trim && !(AMP_ABL & 4)) {
+#else
         if (P.do_trim) {
+#endif
 #pragma unroll
             for (int k = 0; k < F_NP; ++k) {
                 uint32_t p = (uint32_t)k + rot;
@@ -407,17 +607,17 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
 
         F_STAMP(3);          // window scan
         // ---- quality clip, results (A:589-686) ------------------------------------------------------------------
-        bool general = (taken || (solo && lane == 0)) && !simple;
-        bool counted = false, stored = false;
-        uint32_t ncig = 0, cw[3] = {0u, 0u, 0u};
+        bool general = (taken || (solo && lane == 0)) && !shaped;
+        bool stored = false;
+        uint32_t ncig = 0, cw[5] = {0u, 0u, 0u, 0u, 0u};
         int32_t reflen = 0;
-        if (simple) {
+        if (shaped) {
             // the read's first quality byte (0xFF = QUAL '*') is byte phi of piece 0, which sits in slot (np - rot) mod np
             uint32_t fb = phi ? q16[0].z : q16[0].x;
 #pragma unroll
             for (int k = 1; k < F_NP; ++k) fb = ((uint32_t)k + rot == np) ? (phi ? q16[k].z : q16[k].x) : fb;
-            if ((fb & 0xFFu) == 0xFFu) {
-                general = true;                   // QUAL '*': the generic code reports it (A:561-562, A:718)
+            if ((fb & 0xFFu) == 0xFFu || s.punt) {
+                general = true;                   // QUAL '*': the generic code reports it (A:561-562, A:718); a shape the closed forms leave
             } else {
                 if (scan) {
                     int32_t iq;
@@ -436,91 +636,185 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
                             if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
                         }
                     }
-                    trim_quality_apply_simple(ts, rev, iq, qlen, sc);
+                    cig2_trim_quality(ts, rev, iq, qlen, s);
                 }
-                if (!ts.err) {
-                    if (sc.a > 0) cw[ncig++] = ((uint32_t)sc.a << 4) | OP_S;
-                    if (sc.m > 0) cw[ncig++] = ((uint32_t)sc.m << 4) | sc.op;
-                    if (sc.c > 0) cw[ncig++] = ((uint32_t)sc.c << 4) | OP_S;
-                    reflen = sc.m > 0 ? sc.m : 1;
+                if (s.punt) {
+                    general = true;
+                } else {
+                    if (!ts.err) {
+                        // [S a][op m1][I|D k][op m2][S c], absent parts left out: slot `ncig` takes the next part
+                        const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op,
+                                                  ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D), ((uint32_t)s.m2 << 4) | s.op,
+                                                  ((uint32_t)s.c << 4) | OP_S};
+                        const bool has[5] = {s.a > 0, s.m1 > 0, s.kind != 0, s.kind != 0, s.c > 0};
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) {
+                            if (has[t]) {
+#pragma unroll
+                                for (int j = 0; j < 5; ++j) cw[j] = ncig == (uint32_t)j ? part[t] : cw[j];
+                                ++ncig;
+                            }
+                        }
+                        reflen = s.ref_len();
+                    }
+                    stored = true;
+                    if (ts.err) ++n_err;
                 }
-                stored = true;
-                if (ts.err) ++n_err;
-                counted = !ts.err && P.do_count;
             }
         }
-
+        const bool counted = stored && !ts.err && P.do_count;
         F_STAMP(4);          // quality clip, results
-        // ---- counting (A:709-753 for a read without indels) -----------------------------------------------------
-        uint32_t redo = 0;                        // pieces (slots) the careful loop has to do
-        const int32_t qa = counted ? sc.a + (int32_t)phi : 0, qb = counted ? qa + sc.m : 0;      // piece coordinates
-        if (P.do_count) {
-            const int32_t dbase = ts.pos - pw_base - qa;                   // window offset of piece coordinate 0
+        // ---- counting (A:709-753): the counted query ranges [qa1, qb1) and [qa2, qb2) in piece coordinates, the window
+        // offset of piece coordinate 0 for each of them ------------------------------------------------------------------
+        const bool two = counted && s.kind != 0;
+        const int32_t qa1 = counted ? s.a + (int32_t)phi : 0, qb1 = counted ? qa1 + s.m1 : 0;
+        const int32_t qa2 = two ? qb1 + (s.kind == 1 ? s.k : 0) : qb1, qb2 = two ? qa2 + s.m2 : qa2;
+        const int32_t pos2 = ts.pos + s.m1 + (s.kind == 2 ? s.k : 0);              // reference position of the second segment
+        bool bad_extra = false;
+        // deletion: '-' at each of its positions (A:714-715), through the block's window
+        if (two && s.kind == 2) {
+            for (int32_t j = 0; j < s.k; ++j) {
+                const int32_t r = ts.pos + s.m1 + j;
+                const uint32_t d = (uint32_t)(r - bw_base);
+                if ((uint32_t)r >= G) bad_extra = true;
+                else if (d < (uint32_t)F_BW) lds_add_nt(bwin + 4 * F_BW + d, 1u);
+                else atomicAdd(&counts[(size_t)r * AMP_NSYM + 5], 1u);
+            }
+        }
+        // insertion (A:730-748): one event per maximal run of good-quality inserted bases (cig2_indels in amp_read.hpp;
+        // the low base that ends a run is consumed, which changes nothing: it would be skipped anyway)
+        {
+            uint32_t good = 0;
+            if (two && s.kind == 1) {
+                const uint32_t o0 = ok_bits4(iq0.x, mqb) >> 7, o1 = ok_bits4(iq0.y, mqb) >> 7, o2 = ok_bits4(iq1.x, mqb) >> 7, o3 = ok_bits4(iq1.y, mqb) >> 7;
+                // byte flags -> bits: bit b of a dword's nibble = bit 8 b of the flags
+                auto nib = [](uint32_t o) { return ((o * 0x00204081u) >> 21) & 0xFu; };
+                const uint32_t m16 = nib(o0) | (nib(o1) << 4) | (nib(o2) << 8) | (nib(o3) << 12);
+                good = (m16 >> (uint32_t)(q_ins & 7)) & ((1u << s.k) - 1u);
+            }
+            uint32_t runs = good & ~(good << 1);                              // first base of every run
+            const unsigned long long em = __ballot(runs != 0u);
+            if (em) {
+                // Event slots come from the wave's GRANULE of the list: one returning atomic on the shard's cursor
+                // reserves F_EVGRAN slots (a reservation per tile would serialise the chip on a few addresses)
+                const uint32_t total = (uint32_t)__popcll(em);
+                if (total > ev_left) {
+                    pad_events();
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(&ctr[16 + ev_shard], (unsigned long long)F_EVGRAN);
+                    ev_base = __shfl(nb, 0); ev_left = F_EVGRAN;
+                }
+                if (runs) {
+                    const int32_t q0 = s.a + s.m1, r2 = ts.pos + s.m1, ref_end = ts.pos + s.m1 + s.m2;
+                    // the lane's first run takes its slot of the granule; further runs of one insertion (rare) go the slow way
+                    const unsigned long long slot = ev_base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+                    const uint32_t rid = (uint32_t)(read_base + (uint64_t)i);
+                    bool firstrun = true;
+                    while (runs) {
+                        const int32_t js = __builtin_ctz(runs);
+                        runs &= runs - 1u;
+                        const int32_t je = js + __builtin_ctz(~(good >> js));
+                        int32_t elo, ehi;
+                        py_slice(q0 + js - 1, q0 + je, (int32_t)lseq, elo, ehi);                   // A:738
+                        int32_t ins_pos = je == s.k ? r2 : ref_end;                                // A:742 / A:739-740
+                        ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                               // A:744
+                        const bool inside = (uint32_t)ins_pos < G;
+                        if (!inside) bad_extra = true;
+                        if (firstrun) {
+                            if ((long long)slot < eb.cap) ev_list[slot] = inside ? amp_ins_event{ins_pos, rid, elo, ehi} : amp_ins_event{-1, 0u, 0, 0};
+                            if (inside) {
+                                const uint32_t d = (uint32_t)(ins_pos - bw_base);
+                                if (d < (uint32_t)F_BW) lds_add_nt(bwin + 5 * F_BW + d, 1u);
+                                else atomicAdd(&eb.ins_at[ins_pos], 1u);
+                            }
+                        } else if (inside) {
+                            eb.record(ins_pos, rid, elo, ehi);
+                        }
+                        firstrun = false;
+                    }
+                }
+                ev_base += total; ev_left -= total;
+            }
+        }
+        uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F_NP = group B
+        // group B: the part of the second segment that shares a piece with the first
+        int32_t xbe = 0, jb = 0;
+        bool has_b = false;
+        if (two) {
+            const int32_t jstar = (qb1 - 1) & ~15;                   // the piece that holds the first segment's last base
+            has_b = jstar + 16 > qa2 && qb2 > qa2;
+            xbe = qb2 < jstar + 16 ? qb2 : jstar + 16;
+            jb = g_b + (int32_t)phi;
+        }
+        // The bases go into the wave's packed window, F_PW positions from pw_base.  Reads of one tile usually lie within a
+        // few positions of each other; where the batch steps from one pile of reads to the next they do not, and the
+        // tile is counted in PASSES: every pass takes the lanes whose counted positions all lie inside the window, then the
+        // window is folded and anchored again at the first lane that is left.  (Without this the lanes behind the step went
+        // through the careful loop, base by base from global memory: one such tile cost as much as a dozen others.)
+        const int32_t end_pos = two ? pos2 + s.m2 : ts.pos + s.m1;                 // one past the last counted position
+        bool todo = counted;
+#if defined(AMP_DEV) && defined(AMP_ABL)
+        if (AMP_ABL & 2) todo = false;
+#endif
+        for (bool first_pass = true;; first_pass = false) {
+            const unsigned long long tm = __ballot(todo);
+            if (!tm) break;
+            const int lead = __builtin_ctzll(tm);                                   // sorted input: the smallest position that is left
+            if (!first_pass) {
+                fold();
+                const int32_t lead_pos = __builtin_amdgcn_readlane(pos, lead);
+                pw_base = (lead_pos < 16 ? 0 : lead_pos - 16) & ~15; pw_tiles = 1;
+                pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+            }
+            // pieces are 16 positions wide: 16 positions of slack at both ends.  The lead lane always goes (a piece of
+            // its read that does not fit -- at the very end of the reference -- is left to the careful loop)
+            const bool fits = ts.pos - pw_base >= 16 && end_pos - pw_base + 16 <= (int32_t)pw_lim;
+            const bool now = todo && (fits || lane == lead);
+            const int32_t a1 = now ? qa1 : 0, b1 = now ? qb1 : 0, a2 = now ? qa2 : 0, b2 = now ? qb2 : 0;
+            const int32_t dbase1 = ts.pos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
+            if (__ballot(has_b && now)) {
+                if (has_b && now && count_piece(make_uint4(bq0.x, bq0.y, bq1.x, bq1.y), bsq, jb, qa2, xbe, dbase2)) redo |= 1u << F_NP;
+            }
 #pragma unroll
             for (int k = 0; k < F_NP; ++k) {
                 uint32_t p = (uint32_t)k + rot;
                 p = p >= np ? p - np : p;
                 p = (uint32_t)k < np ? p : np;
                 const int32_t j0 = (int32_t)(p * 16u);
-                int32_t klo = qa - j0, khi = qb - j0;
-                klo = klo < 0 ? 0 : klo; khi = khi > 16 ? 16 : khi;
-                if (khi > klo) {                                            // some base of the piece is counted
-                    const int32_t d0 = dbase + j0;                          // window offset of the piece's base 0
-                    const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);   // khi <= 16
-                    // per base (byte): 1 = counted (quality and range), code, shift count of its counter byte
-                    uint32_t f[4], cb[4], sh[4];
-                    f[0] = (ok_bits4(q16[k].x, mqb) >> 7) & nibble_to_bytes(rng, 0);
-                    f[1] = (ok_bits4(q16[k].y, mqb) >> 7) & nibble_to_bytes(rng, 1);
-                    f[2] = (ok_bits4(q16[k].z, mqb) >> 7) & nibble_to_bytes(rng, 2);
-                    f[3] = (ok_bits4(q16[k].w, mqb) >> 7) & nibble_to_bytes(rng, 3);
-                    spread_codes(s8[k], cb);
-                    uint32_t bad = 0;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) { bad |= (not_acgt(cb[d]) >> 7) & f[d]; sh[d] = shift_bytes(cb[d]); }
-                    // (a counted N is rare -- N calls come with low qualities -- and takes the careful loop too)
-                    const bool safe = bad == 0u && pw_lim >= 16u && (uint32_t)d0 <= pw_lim - 16u;
-                    if (safe) {
-                        lds_u8 *const wb = wrep + (uint32_t)d0 * 4u;
-                        lds_add((lds_u32 *)(wb + 0), shl_byte<0>(sh[0], f[0]));   lds_add((lds_u32 *)(wb + 4), shl_byte<1>(sh[0], f[0]));
-                        lds_add((lds_u32 *)(wb + 8), shl_byte<2>(sh[0], f[0]));   lds_add((lds_u32 *)(wb + 12), shl_byte<3>(sh[0], f[0]));
-                        lds_add((lds_u32 *)(wb + 16), shl_byte<0>(sh[1], f[1]));  lds_add((lds_u32 *)(wb + 20), shl_byte<1>(sh[1], f[1]));
-                        lds_add((lds_u32 *)(wb + 24), shl_byte<2>(sh[1], f[1]));  lds_add((lds_u32 *)(wb + 28), shl_byte<3>(sh[1], f[1]));
-                        lds_add((lds_u32 *)(wb + 32), shl_byte<0>(sh[2], f[2]));  lds_add((lds_u32 *)(wb + 36), shl_byte<1>(sh[2], f[2]));
-                        lds_add((lds_u32 *)(wb + 40), shl_byte<2>(sh[2], f[2]));  lds_add((lds_u32 *)(wb + 44), shl_byte<3>(sh[2], f[2]));
-                        lds_add((lds_u32 *)(wb + 48), shl_byte<0>(sh[3], f[3]));  lds_add((lds_u32 *)(wb + 52), shl_byte<1>(sh[3], f[3]));
-                        lds_add((lds_u32 *)(wb + 56), shl_byte<2>(sh[3], f[3]));  lds_add((lds_u32 *)(wb + 60), shl_byte<3>(sh[3], f[3]));
-                    } else {
-                        redo |= 1u << k;
-                    }
-                }
+                const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
+                if (count_piece(q16[k], s8[k], j0, second ? a2 : a1, second ? b2 : b1, second ? dbase2 : dbase1)) redo |= 1u << k;
             }
+            todo = todo && !now;
         }
         F_STAMP(5);          // counting
+        bool want_status = bad_extra;
         if (__ballot(redo != 0u)) {
             // careful loop (rare): bases of the flagged pieces one by one, straight from memory into the 32-bit counters
-            bool bad = false;
             if (redo) {
-                const int32_t qaq = sc.a, qbq = sc.a + sc.m;               // query indices
+                const int32_t a1 = qa1 - (int32_t)phi, b1 = qb1 - (int32_t)phi, a2 = qa2 - (int32_t)phi, b2 = qb2 - (int32_t)phi;   // query indices
+                auto careful = [&](int32_t x0, int32_t x1, int32_t qa_q, int32_t rp0) {
+                    for (int32_t q = x0; q < x1; ++q) {
+                        if ((int32_t)qrow[q] < mq) continue;
+                        const uint32_t sb = srow[q >> 1];
+                        const uint32_t col = col_of_code((q & 1) ? (sb & 15u) : (sb >> 4));
+                        const int32_t rp = rp0 + (q - qa_q);
+                        const uint32_t d = (uint32_t)(rp - bw_base);
+                        if (col > 4u || (uint32_t)rp >= G) want_status = true;
+                        else if (d < (uint32_t)F_BW && col < (uint32_t)F_NPL) lds_add_nt(bwin + col * F_BW + d, 1u);
+                        else atomicAdd(&counts[(size_t)rp * AMP_NSYM + col], 1u);
+                    }
+                };
                 for (int k = 0; k < F_NP; ++k) {
                     if (!((redo >> k) & 1u)) continue;
                     uint32_t p = (uint32_t)k + rot;
                     p = p >= np ? p - np : p;
                     const int32_t j0 = (int32_t)(p * 16u) - (int32_t)phi;
-                    for (int32_t q = j0 < qaq ? qaq : j0; q < j0 + 16 && q < qbq; ++q) {
-                        if ((int32_t)qrow[q] < mq) continue;
-                        const uint32_t sb = srow[q >> 1];
-                        const uint32_t col = col_of_code((q & 1) ? (sb & 15u) : (sb >> 4));
-                        const int32_t rp = ts.pos + (q - qaq);
-                        const uint32_t d = (uint32_t)(rp - bw_base);
-                        if (col > 4u || (uint32_t)rp >= G) bad = true;
-                        else if (d < (uint32_t)F_BW && col < (uint32_t)F_NPL) lds_add(bwin + col * F_BW + d, 1u);
-                        else atomicAdd(&counts[(size_t)rp * AMP_NSYM + col], 1u);
-                    }
+                    const bool second = j0 + (int32_t)phi >= qb1;
+                    const int32_t sa = second ? a2 : a1, sb_ = second ? b2 : b1;
+                    careful(j0 < sa ? sa : j0, j0 + 16 < sb_ ? j0 + 16 : sb_, sa, second ? pos2 : ts.pos);
                 }
+                if ((redo >> F_NP) & 1u) careful(a2, xbe - (int32_t)phi, a2, pos2);
             }
-            redo = bad ? 1u : 0u;
-        } else {
-            redo = 0u;
         }
 
         // ---- results and hand-over to the general pass: kept for the next turn of the loop ---------------------------
@@ -528,22 +822,31 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
             uint32_t entry = 0;
             bool has = false;
             if (general) { entry = (uint32_t)i; has = true; }
-            else if (counted && redo) { entry = (uint32_t)i | GL_STATUS_ONLY; has = true; }   // a base could not be counted: exact status wanted
-            pend = Pend{i, c0, ts.pos, reflen, ncig, cw[0], cw[1], cw[2], (uint32_t)ts.err, ts.err ? 0u : ts.flags, entry, stored, has};
+            else if (counted && want_status) { entry = (uint32_t)i | GL_STATUS_ONLY; has = true; }   // a base could not be counted: exact status wanted
+            pend = Pend{i, c0, ts.pos, reflen, ncig, cw[0], cw[1], cw[2], cw[3], cw[4], (uint32_t)ts.err, ts.err ? 0u : ts.flags, entry, stored, has};
         }
         F_STAMP(6);          // careful loop
-        hA = hB; gA = gB; xA = xB; m0A = m0B; hB = hC;
-        i0 = i1; i1 = i2;
     }
+    F_EPI(0);
     store_pending(pend);
+    pad_events();
+    F_EPI(1);
     if (pw_tiles && wbeg < wend) fold();
-
+    F_EPI(2);
     __syncthreads();
-    for (int i = tid; i < F_NPL * F_BW; i += F_WAVES * 64) {
+#if defined(AMP_DEV) && defined(AMP_ABL)
+    if (AMP_ABL & 16) return;
+#endif
+    for (int i = tid; i < F_BPL * F_BW; i += F_WAVES * 64) {
         const uint32_t v = bwin[i];
         if (v) {
-            const int sym = i / F_BW, d = i - sym * F_BW;
-            if ((uint32_t)(bw_base + d) < G) atomicAdd(&counts[(size_t)(bw_base + d) * AMP_NSYM + sym], v);
+            const int pl = i / F_BW, d = i - pl * F_BW;
+            const uint32_t p = (uint32_t)(bw_base + d);
+            if (p < G) {
+                if (pl < F_NPL) atomicAdd(&counts[(size_t)p * AMP_NSYM + pl], v);
+                else if (pl == 4) atomicAdd(&counts[(size_t)p * AMP_NSYM + 5], v);      // '-'
+                else atomicAdd(&eb.ins_at[p], v);
+            }
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
@@ -556,7 +859,7 @@ k_fast(KParams P, amp_dev_reads rd, DevOut out, uint32_t *counts, unsigned long 
 // read order is kept.
 __global__ void __launch_bounds__(256)
 k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt, int reads_per_block, int64_t n_reads,
-           uint32_t *__restrict__ dense, GenGeo *geo, uint32_t gen_grid) {
+           uint32_t *__restrict__ dense, GenGeo *geo, uint32_t gen_grid, unsigned long long *ctr) {
     __shared__ uint32_t s_part[4];
     const int tid = threadIdx.x;
     uint32_t acc = 0;
@@ -577,22 +880,23 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
         tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;
         if (tpb < (uint32_t)T_WAVES) tpb = T_WAVES;
         geo->n_list = n_list; geo->tpb = tpb; geo->n_seg = (tiles + tpb - 1) / tpb; geo->pad = 0;
+        ctr[7] = n_list;                          // (amp_debug_counters: reads of the last batch that took the general pass)
     }
 }
 
-static inline int fast_launch(const KParams &P, const amp_dev_reads &rd, const DevOut &out, uint32_t *counts, unsigned long long *ctr,
-                              uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, hipStream_t stream) {
+static inline int fast_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out, uint32_t *counts,
+                              const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, hipStream_t stream, uint32_t *dbg) {
     const unsigned g = (unsigned)fg.grid, t = F_WAVES * 64;
     const int rpb = (int)fg.rpb;
     switch (P.window) {
-        case 1: k_fast<1><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 2: k_fast<2><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 3: k_fast<3><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 4: k_fast<4><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 5: k_fast<5><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 6: k_fast<6><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        case 7: k_fast<7><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
-        default: k_fast<8><<<g, t, 0, stream>>>(P, rd, out, counts, ctr, glist, gcnt, rpb); break;
+        case 1: k_fast<1><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 2: k_fast<2><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 3: k_fast<3><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 4: k_fast<4><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 5: k_fast<5><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 6: k_fast<6><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 7: k_fast<7><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        default: k_fast<8><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
     }
     return (int)hipGetLastError();
 }

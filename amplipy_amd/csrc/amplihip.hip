@@ -981,7 +981,10 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned long long mx = 0;
         for (int s = 0; s < EV_SHARDS; ++s) mx = std::max(mx, h[16 + s]);
-        const int64_t need = (int64_t)(mx + h[1]);          // any shard may receive every new event
+        // any shard may receive every new event; the fast kernel reserves list slots a granule at a time (a refill
+        // leaves fewer slots unused than the tile that caused it needs, plus one open granule per wave at the end)
+        const FastGrid fgb = fast_grid(n, c->n_cu);
+        const int64_t need = (int64_t)(mx + 2 * h[1]) + fgb.grid * F_WAVES * (int64_t)F_EVGRAN;
         if (need > c->ev_cap) HIPCHK(c, grow_events(c, std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2)));
     }
     KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end};
@@ -1033,12 +1036,19 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        if (fast_launch(P, *rd, out, c->d_counts, c->d_ctr, glist, gcnt, fg, c->stream) != 0) {
+        if (fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid);
+        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr);
         HIPCHK(c, hipGetLastError());
+#ifdef AMP_DEV
+        if (c->phases & 0x100u) {           // stamps of the general pass alone: the fast kernel's are dropped
+            HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 12 * sizeof(unsigned long long), c->stream));
+            k_tile<true, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
+                                                                                       gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
+        } else
+#endif
         k_tile<false, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
                                                                                     gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
         HIPCHK(c, hipGetLastError());

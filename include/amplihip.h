@@ -207,7 +207,9 @@ int amp_debug_counters(amp_ctx *ctx, uint64_t *out16);
 int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks);
 /* Pre-size the insertion-event buffer.  Without it every amp_process_batch* call first runs
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
- * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short. */
+ * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short.
+ * `cap` is per list shard (there are 8); size it for the events of a batch plus 64 slots for
+ * every 64 reads' worth of slack: waves reserve list slots 64 at a time and leave some unused. */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
 /* 2 (default) = fused tile kernel; 1 = one-lane-per-read kernels and 3 = the same work cut into three
  * kernels (k_trim, k_scan, k_tile<SPLIT>), both kept for on-GPU A/B checks (all three give identical

@@ -7,10 +7,11 @@ from amplipy_amd import abi, lib, synth, synth_torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--depth", type=int, default=10000); ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--variant", type=int, default=4); ap.add_argument("--check", action="store_true")
+ap.add_argument("--indel-frac", type=float, default=0.10)
 a = ap.parse_args()
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme(); G = g.size
 n = synth.reads_for_depth(a.depth)
-b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0"); torch.cuda.synchronize()
+b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0", indel_frac=a.indel_frac); torch.cuda.synchronize()
 mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
 e = lib.Engine(G); e.set_kernel_variant(a.variant)
 e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True); e.reserve_events(max(1 << 20, n // 4))
@@ -23,15 +24,48 @@ ms = []
 for it in range(a.iters):
     e.reset(); e.process_device(rd, 0, dev_out); e.sync(); ms.append(e.last_kernel_ms())
 print("variant %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.depth, n), ["%.3f/%.3f" % m for m in ms])
-if os.environ.get("AMP_STAMPS"):
+if not os.environ.get("AMP_STAMPS"): print("general-pass reads of the last launch:", int(e.debug_counters()[7]))
+if os.environ.get("AMP_STAMPS") not in (None, "", "0") and not os.environ.get("AMPLIHIP_PHASES"):
     dc = e.debug_counters()
-    tot = float(sum(int(x) for x in dc[8:15])) or 1.0
-    print("phase shares (header wait, bytes wait, staging, clips+scan, qclip+outputs, count, careful+handover):",
-          ["%.1f%%" % (100.0 * int(x) / tot) for x in dc[8:15]], "cycles/tile-wave %.0f" % (tot / a.iters / ((n + 63) // 64)))
-if a.check:
-    from oracle import oracle
-    hb = b.to_host()
-    ref = oracle.process(hb, G, mn, mx, mpl, 20, 4)
-    assert np.array_equal(e.counts(), ref.counts), "counts differ"
-    assert np.array_equal(out["new_pos"].cpu().numpy(), ref.trim.new_pos)
-    print("check ok")
+    tot = float(sum(int(x) for x in dc[9:15])) or 1.0
+    nt = (n + 63) // 64
+    nw = 8 * ((n + 8191) // 8192)
+    print("k_fast whole kernel per wave: %.0f shader cycles = %.1f us of the 100 MHz clock -> shader clock %.0f MHz; tile loop %.0f cycles of them"
+          % (int(dc[8]) / nw, int(dc[15]) / nw / 100.0, 100.0 * int(dc[8]) / max(int(dc[15]), 1), tot / nw))
+    M = (1 << 64) - 1
+    print("k_fast waves: shortest %.1f us, longest %.1f us; first start to last end %.1f us" % ((M - int(dc[5])) / 100.0, int(dc[4]) / 100.0, (int(dc[7]) - (M - int(dc[6]))) / 100.0))
+    w = e.debug_blocks().reshape(-1, 8)[:nw // 8].astype(np.int64)
+    dur = w[:, 0].reshape(-1, 1) / 100.0; st = (w[:, 1] - w[:, 1].min()).reshape(-1, 1) / 100.0
+    bd = dur.max(axis=1)
+    print("per block (us): start offset min/max %.1f/%.1f; duration min %.1f median %.1f max %.1f; waves of one block differ by up to %.1f"
+          % (st.min(), st.max(), bd.min(), np.median(bd), bd.max(), (dur.max(axis=1) - dur.min(axis=1)).max()))
+    print("block duration by block index modulo 8 (XCD):", [round(float(bd[k::8].mean()), 1) for k in range(8)])
+    print("block durations in block order:", [int(x) for x in bd])
+    rpb = 8192
+    pos_h = b.pos.cpu().numpy().astype(np.int64); fl = b.flag.cpu().numpy().astype(np.int64) & 0xFFFF
+    nb_ = bd.size
+    feat = {"reverse fraction": [], "position span": [], "distinct starts": [], "first position": []}
+    for k in range(nb_):
+        pp = pos_h[k * rpb:(k + 1) * rpb]; ff = fl[k * rpb:(k + 1) * rpb]
+        feat["reverse fraction"].append(float(((ff & 16) != 0).mean())); feat["position span"].append(float(pp[-1] - pp[0]))
+        feat["distinct starts"].append(float(np.unique(pp).size)); feat["first position"].append(float(pp[0]))
+    for k_, v in feat.items():
+        print("  corr(duration, %s) = %.2f" % (k_, np.corrcoef(bd, np.array(v))[0, 1]))
+    ph = w[:, 2:8].astype(np.float64)                                    # wave 0 of every block: cycles per tile (16 tiles, stored >> 4)
+    so = np.argsort(bd)
+    print("  phases (cycles per tile: top wait, rows+clips+issue, scan, qclip, count, careful) of the 30 fastest blocks:", [int(x) for x in ph[so[1:31]].mean(axis=0)])
+    print("  ... of the 30 slowest blocks:", [int(x) for x in ph[so[-30:]].mean(axis=0)])
+    raw = e.debug_blocks().reshape(-1)
+    pw = raw[2048:2048 + nw * 6].reshape(-1, 8, 6).astype(np.float64) * 16 / 2.29e3      # us per wave and phase
+    for bidx in list(so[-3:]) + list(so[1:3]):
+        print("  block %d (%.0f us): per wave us: top wait %s | rows, clips, issue %s | scan %s | quality clip %s | count %s | careful, hand-over %s" % ((bidx, bd[bidx]) + tuple([int(x) for x in pw[bidx, :, k]] for k in range(6))))
+    slow = np.argsort(bd)[-6:]; fast = np.argsort(bd)[:6]
+    for name, idx in (("slowest", slow), ("fastest", fast)):
+        print("  %s blocks:" % name, [(int(i), int(bd[i]), round(feat["reverse fraction"][i], 2), int(feat["position span"][i]), int(feat["distinct starts"][i])) for i in idx])
+    print("k_fast phases, shader cycles per tile and wave (last launch): top wait %.0f | rows, primer clips, next tile issued %.0f | scan %.0f | quality clip, results %.0f | count %.0f | careful, hand-over %.0f | total %.0f"
+          % tuple([int(dc[8 + k]) / nt for k in (1, 2, 3, 4, 5, 6)] + [tot / nt]))
+if os.environ.get("AMPLIHIP_PHASES"):
+    dc = e.debug_counters()
+    tot = float(sum(int(x) for x in dc[8:13])) or 1.0
+    print("general pass (k_tile<LIST>) stamps: tiles %d; cycles per tile P1 %.0f P2 %.0f P3 %.0f P4 %.0f tail %.0f; waves %d mean loop %.0f cyc, wait at final barrier %.0f cyc; block mean %.0f cyc"
+          % (int(dc[13]), *[int(dc[8 + k]) / max(int(dc[13]), 1) for k in range(5)], int(dc[15]), int(dc[6]) / max(int(dc[15]), 1), int(dc[7]) / max(int(dc[15]), 1), int(dc[4]) / max(int(dc[15]) // 8, 1)))
