@@ -58,9 +58,10 @@ static inline FastGrid fast_grid(int64_t n_reads, int n_cu) {
 #ifndef AMP_F_BPC
 #define AMP_F_BPC 1
 #endif
-    // AMP_F_BPC blocks per CU (one is resident); a wave gets at least two tiles of 64 reads
+    // AMP_F_BPC blocks per CU (one is resident): a block owns a contiguous range of whole tiles of 64 reads, which its
+    // waves take one by one (at least two tiles per wave)
     int64_t rpb = (n_reads + AMP_F_BPC * (int64_t)n_cu - 1) / (AMP_F_BPC * (int64_t)n_cu);
-    rpb = ((rpb + F_WAVES * 64 - 1) / (F_WAVES * 64)) * (F_WAVES * 64);
+    rpb = ((rpb + 63) / 64) * 64;
     if (rpb < 2 * F_WAVES * 64) rpb = 2 * F_WAVES * 64;
     return FastGrid{(n_reads + rpb - 1) / rpb, rpb};
 }
@@ -257,6 +258,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     __shared__ uint4 s_stage[F_WAVES][(F_PAD + F_STAGE + 16) / 16];   // per wave: the tile's quality bytes, then its packed bases
     __shared__ uint32_t s_pwin[F_WAVES][F_REP * F_REPW];              // per wave: packed counters, byte c of a word = base c (A C G T)
     __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
+    __shared__ uint32_t s_ticket, s_gcur;                             // next tile of the block to hand out; entries of its general list
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     F_STAMP_DECL;
@@ -267,6 +269,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const pwin = (lds_u32 *)s_pwin[wave];
     for (int i = tid; i < F_BPL * F_BW; i += F_WAVES * 64) bwin[i] = 0;
     for (int i = lane; i < F_REP * F_REPW; i += 64) pwin[i] = 0;
+    if (tid == 0) { s_ticket = 0; s_gcur = 0; }
     // the block's window: anchored 16 positions left of its first read (sorted input: nothing of this block starts
     // left of that read)
     int32_t bw_base = rb < n ? rd.pos[rb] : 0;
@@ -278,10 +281,17 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const uint32_t thr = mqc * (uint32_t)W;
     const uint32_t mqb = (uint32_t)mq * 0x01010101u;             // mq <= 128 (the host sends other runs to the general kernel)
     const uint32_t G = (uint32_t)P.ref_len;
-    const int64_t per_wave = reads_per_block / F_WAVES;
-    const int64_t wbeg = rb + (int64_t)wave * per_wave;
-    int64_t wend = wbeg + per_wave;
-    wend = wend < re ? wend : re;
+    // Tiles are handed out one by one (a counter in LDS): the waves of a block do not run at the same speed -- of the two
+    // waves that share a SIMD the older one gets most of the issue slots -- and with equal shares the CU would idle while
+    // the slower half finishes.  A wave holds three tickets: the tile it computes, the tile whose bytes are on their way
+    // and the tile whose header is being read.
+    const uint32_t n_tb = re > rb ? (uint32_t)((re - rb + 63) / 64) : 0u;
+    auto take_ticket = [&]() {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    const int64_t wend = re;                                        // (a tile's lanes past the block's reads are idle)
     unsigned long long n_err = 0;
     // lane constants of the bank plan (see the head of this file)
     const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
@@ -331,7 +341,20 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     // header of tile t + 2 is being read.  Loads of one tile form a chain header -> CIGAR words -> primer-table entries;
     // each link is issued one stage after the link before it has been waited for, so nothing in the loop waits for a
     // load it has just issued ------------------------------------------------------------------------------------------
-    struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };
+    struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };      // as loaded
+    // ... and as kept between tiles: lf = l_seq (saturated at 0xFFFF: anything that long leaves the fast path anyway) |
+    // paired << 16 | reverse << 17 | the template-length test of A:452 << 18 | number of CIGAR ops (saturated at 7) << 19
+    struct HdrP { int32_t pos; uint32_t lf, c0, o8;
+        __device__ uint32_t lseq() const { return lf & 0xFFFFu; }
+        __device__ uint32_t nops() const { return (lf >> 19) & 7u; }
+        __device__ uint32_t flag() const { return ((lf >> 16) & 1u) | (((lf >> 17) & 1u) << 4); }      // bits 0x1 and 0x10 of FLAG
+        __device__ bool isize_flag() const { return (lf >> 18) & 1u; } };
+    auto pack_hdr = [&](const Hdr &h) {
+        const uint32_t n = h.c1 - h.c0, at = (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen);
+        const bool isz = ((int64_t)at - P.max_primer_len) > (int64_t)h.lseq;                                  // A:452
+        return HdrP{h.pos, (h.lseq > 0xFFFFu ? 0xFFFFu : h.lseq) | ((h.flag & 1u) << 16) | (((h.flag >> 4) & 1u) << 17) | ((isz ? 1u : 0u) << 18) | ((n > 7u ? 7u : n) << 19),
+                    h.c0, h.o8};
+    };
     struct Cg { uint32_t w0, w1, w2; };
     struct Geo { uint32_t np, phi, row, Tq; int ntake; bool solo, taken, fastq; };
     struct Tabs { int32_t L, R; };
@@ -347,24 +370,26 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         return h;
     };
     // the first three CIGAR words (lanes past the wave's reads have c1 == c0)
-    auto load_cig = [&](const Hdr &h) {
+    auto load_cig = [&](const HdrP &h) {
         Cg c{0u, 0u, 0u};
-        const uint32_t nops = h.c1 - h.c0;
+        const uint32_t nops = h.nops();
         if (nops >= 1u) c.w0 = rd.cig[h.c0];
         if (nops == 3u) { c.w1 = rd.cig[h.c0 + 1]; c.w2 = rd.cig[h.c0 + 2]; }
         return c;
     };
-    // the tile: the leading reads whose bytes form one run of at most F_STAGE quality bytes
-    auto geometry = [&](const Hdr &h, int64_t t0, uint32_t &m0) {
+    // the tile's run: the bytes of its leading reads, at most F_STAGE quality bytes (64 reads of up to 152 bases always
+    // fit; the lanes behind a longer read do not, and go to the general pass like the long read itself)
+    auto geometry = [&](const HdrP &h, int64_t t0, uint32_t &m0) {
         Geo g;
         const bool valid = t0 + lane < wend;
-        const bool shortq = valid && h.lseq >= 1u && h.lseq <= (uint32_t)F_MAXLEN;
+        const uint32_t hl = h.lseq();
+        const bool shortq = valid && hl >= 1u && hl <= (uint32_t)F_MAXLEN;
         // pieces start phi bases before the read (its coordinates below are shifted by phi); np of them cover it
         g.phi = shortq ? phi_lane : 0u;
-        g.np = shortq ? (h.lseq + g.phi + 15u) >> 4 : 1u;
+        g.np = shortq ? (hl + g.phi + 15u) >> 4 : 1u;
         m0 = __builtin_amdgcn_readfirstlane(h.o8);
         g.row = (h.o8 - m0) * 8u;                                            // byte offset of the read's qualities in the run
-        const uint32_t nch = (h.lseq + 7u) >> 3;
+        const uint32_t nch = (hl + 7u) >> 3;
         // a row is read as pieces of 16 bytes: up to 16 bytes past the read's own padded bytes
         const bool fits = valid && h.o8 >= m0 && (h.o8 - m0) <= (uint32_t)(F_STAGE / 8) &&
                           g.row + 8u * nch + (shortq ? 8u : 0u) <= (uint32_t)F_STAGE;
@@ -379,18 +404,18 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     };
     // The shape of a read the fast path takes: one match op ("150M"), or two around ONE insertion / deletion
     // ("70M2I78M", "70M3D80M"); refspan = its reference length (A:451 looks the right table up at its last position)
-    auto shape_of = [&](const Hdr &h, const Cg &c, bool fastq) {
+    auto shape_of = [&](const HdrP &h, const Cg &c, bool fastq) {
         Shape r;
         r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
-        const int nops = (int)(h.c1 - h.c0);
-        r.ok = fastq && (nops == 1 || nops == 3) && cig2_from_words(nops, c.w0, c.w1, c.w2, (int32_t)h.lseq, r.s);
+        const int nops = (int)h.nops();
+        r.ok = fastq && (nops == 1 || nops == 3) && cig2_from_words(nops, c.w0, c.w1, c.w2, (int32_t)h.lseq(), r.s);
         if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
         if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
-        r.refspan = r.s.kind ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : (int32_t)h.lseq;
+        r.refspan = r.s.kind ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : (int32_t)h.lseq();
         return r;
     };
     // the two primer-table entries of A:450-451
-    auto load_tabs = [&](const Hdr &h, const Shape &sh) {
+    auto load_tabs = [&](const HdrP &h, const Shape &sh) {
         Tabs t{-1, -1};
         const bool in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + sh.refspan - 1) < G;
         if (sh.ok && P.do_trim && in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
@@ -423,31 +448,38 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     // Results of a tile are STORED ONE TILE LATER, right behind the wait at the top of the loop: stores and loads
     // retire through one in-order counter, so a store issued at the end of a tile would make that wait
     // last until the store has reached memory.
-    struct Pend { int64_t i; uint32_t slot_lo; int32_t pos, reflen; uint32_t ncig, cw0, cw1, cw2, cw3, cw4, status, flags, entry; bool stored, has; };
-    Pend pend{0, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, false, false};
-    uint32_t gwave = 0;                                             // entries of this wave's segment of the general list
+    // results of a tile, packed: meta = ncig | status << 8 | trim flags << 16 | P_* bits
+    enum : uint32_t { P_STORED = 1u << 24, P_LIST = 1u << 25, P_STATUS_ONLY = 1u << 26 };
+    struct Pend { uint32_t i, slot_lo; int32_t pos, reflen; uint32_t meta, cw0, cw1, cw2, cw3, cw4; };
+    Pend pend{0u, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u};
     auto store_pending = [&](const Pend &r) {
 #if defined(AMP_DEV) && defined(AMP_ABL)
         if (AMP_ABL & 8) return;
 #endif
-        if (r.stored) {
+        const uint32_t ncig = r.meta & 0xFFu;
+        if (r.meta & P_STORED) {
             uint32_t *home = out.new_cig + ((size_t)r.slot_lo + 3 * (size_t)r.i);
-            if (r.ncig > 0u) home[0] = r.cw0;
-            if (r.ncig > 1u) home[1] = r.cw1;
-            if (r.ncig > 2u) home[2] = r.cw2;
-            if (r.ncig > 3u) home[3] = r.cw3;
-            if (r.ncig > 4u) home[4] = r.cw4;
+            if (ncig > 0u) home[0] = r.cw0;
+            if (ncig > 1u) home[1] = r.cw1;
+            if (ncig > 2u) home[2] = r.cw2;
+            if (ncig > 3u) home[3] = r.cw3;
+            if (ncig > 4u) home[4] = r.cw4;
             if (out.new_pos) out.new_pos[r.i] = r.pos;
-            if (out.new_ncig) out.new_ncig[r.i] = r.ncig;
+            if (out.new_ncig) out.new_ncig[r.i] = ncig;
             if (out.ref_len) out.ref_len[r.i] = r.reflen;
-            if (out.trim_flags) out.trim_flags[r.i] = (uint8_t)r.flags;
-            if (out.status) out.status[r.i] = (uint8_t)r.status;
+            if (out.trim_flags) out.trim_flags[r.i] = (uint8_t)(r.meta >> 16);
+            if (out.status) out.status[r.i] = (uint8_t)(r.meta >> 8);
         }
-        // hand-over to the general pass: the wave's own segment of the list, in read order (the general kernel's
-        // window follows the positions of the reads it is given)
-        const unsigned long long m = __ballot(r.has);
-        if (r.has) glist[(size_t)wbeg + gwave + __popcll(m & ((1ull << lane) - 1ull))] = r.entry;
-        gwave += (uint32_t)__popcll(m);
+        // hand-over to the general pass: the block's segment of the list (any order: the general kernel's window follows
+        // the reads it is given, and a block's reads lie within a few hundred positions of each other)
+        const bool has = (r.meta & P_LIST) != 0;
+        const unsigned long long m = __ballot(has);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add((lds_u32 *)&s_gcur, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (has) glist[(size_t)rb + base + __popcll(m & ((1ull << lane) - 1ull))] = r.i | ((r.meta & P_STATUS_ONLY) ? GL_STATUS_ONLY : 0u);
+        }
     };
 
     uint32_t pw_lim = 0;
@@ -460,30 +492,33 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     // after it.  They are renamed to "this tile" at the top of the loop, behind the wait, so that no register with a
     // load in flight is touched between the issue of a tile's loads and that wait (the compiler answers every such
     // touch with s_waitcnt vmcnt(0), which would wait for the bytes just requested).
-    int64_t i0 = wbeg, i1 = wbeg, i2 = wbeg;
+    uint32_t tkN = take_ticket(), tkN2 = 0;
+    int64_t i0 = rb, i1 = rb + 64 * (int64_t)tkN, i2 = rb;
     int tile_no = 0; (void)tile_no;
-    Hdr hN = load_hdr(i1), hN2{0, 0, 0u, 0u, 0u, 0u, 0u};
+    HdrP hN = pack_hdr(load_hdr(i1));
+    Hdr hN2{0, 0, 0u, 0u, 0u, 0u, 0u};
     Cg cN = load_cig(hN);
     uint32_t m0N = 0;
     Geo gN = geometry(hN, i1, m0N);
     Bytes xN = issue_bytes(gN, m0N);
-    i2 = i1 + gN.ntake;
+    tkN2 = take_ticket();
+    i2 = rb + 64 * (int64_t)tkN2;
     hN2 = load_hdr(i2);
-    while (i1 < wend) {
+    while (tkN < n_tb) {
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the DMA of this tile's qualities has landed, its other loads too
         F_STAMP(1);
 #if defined(AMP_DEV) && defined(AMP_ABL)
         if (AMP_ABL & 32) { if (((tile_no++) + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
-        const Hdr h = hN;
+        const HdrP h = hN;
         const Cg cA = cN;
         const Geo g = gN;
         const Bytes xA = xN;
-        hN = hN2;
-        i0 = i1; i1 = i2;
+        hN = pack_hdr(hN2);
+        i0 = i1; i1 = i2; tkN = tkN2;
         const int64_t i = i0 + lane;
-        const int32_t pos = h.pos, tlen = h.tlen;
-        const uint32_t lseq = h.lseq, flag = h.flag, c0 = h.c0, o8 = h.o8;
+        const int32_t pos = h.pos;
+        const uint32_t lseq = h.lseq(), flag = h.flag(), c0 = h.c0, o8 = h.o8;
         const uint32_t np = g.np, phi = g.phi;
         const bool solo = g.solo, taken = g.taken, fastq = g.fastq;
         // the primer-table entries of this tile (they hang on its CIGAR words): a short wait behind the row reads below
@@ -530,7 +565,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         TrimState ts{pos, 1, 0u, 0};
         if (shaped && P.do_trim) {
             if (!in_ref) ts.err = AMP_RS_INDEX_REF;
-            else cig2_trim_primers(P, ts, flag, tlen, (int32_t)lseq, s, tA.L, tA.R);
+            else cig2_trim_primers_isize(ts, flag, h.isize_flag(), (int32_t)lseq, s, tA.L, tA.R);
         }
         const bool scan = shaped && P.do_trim && !ts.err && !s.punt;
         // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
@@ -565,17 +600,12 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         // ---- next tile: its CIGAR words and bytes start moving now (its header arrived with this tile's bytes), and the
         // header of the tile behind it.  Nothing below touches them before the wait at the top of the loop.  No branch
         // around the loads of the bytes (behind the wave's last tile they fetch the first bytes of the batch) ---------
-#if defined(AMP_DEV) && defined(AMP_ABL)
-        if (!(AMP_ABL & 64) || i1 < wend) {
-#else
-        {
-#endif
+        tkN2 = take_ticket();                       // (an LDS access the compiler can see: before the DMA is in flight)
+        i2 = rb + 64 * (int64_t)tkN2;
         cN = load_cig(hN);
         gN = geometry(hN, i1, m0N);
         xN = issue_bytes(gN, m0N);
-        i2 = i1 + gN.ntake;
         hN2 = load_hdr(i2);
-        }
         F_STAMP(2);          // staged, rows in registers, primer clips, next tile issued
 
         // ---- sliding-window scan: first failing window start (forward) / last failing window end (reverse) --
@@ -607,7 +637,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 
         F_STAMP(3);          // window scan
         // ---- quality clip, results (A:589-686) ------------------------------------------------------------------
-        bool general = (taken || (solo && lane == 0)) && !shaped;
+        bool general = i < re && !shaped;               // (a lane whose bytes did not fit the run included)
         bool stored = false;
         uint32_t ncig = 0, cw[5] = {0u, 0u, 0u, 0u, 0u};
         int32_t reflen = 0;
@@ -783,6 +813,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 const int32_t j0 = (int32_t)(p * 16u);
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
                 if (count_piece(q16[k], s8[k], j0, second ? a2 : a1, second ? b2 : b1, second ? dbase2 : dbase1)) redo |= 1u << k;
+                __builtin_amdgcn_sched_barrier(0);          // one piece at a time: interleaving them costs registers the kernel does not have
             }
             todo = todo && !now;
         }
@@ -819,11 +850,10 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 
         // ---- results and hand-over to the general pass: kept for the next turn of the loop ---------------------------
         {
-            uint32_t entry = 0;
-            bool has = false;
-            if (general) { entry = (uint32_t)i; has = true; }
-            else if (counted && want_status) { entry = (uint32_t)i | GL_STATUS_ONLY; has = true; }   // a base could not be counted: exact status wanted
-            pend = Pend{i, c0, ts.pos, reflen, ncig, cw[0], cw[1], cw[2], cw[3], cw[4], (uint32_t)ts.err, ts.err ? 0u : ts.flags, entry, stored, has};
+            uint32_t meta = ncig | ((uint32_t)ts.err << 8) | ((ts.err ? 0u : ts.flags) << 16) | (stored ? P_STORED : 0u);
+            if (general) meta |= P_LIST;
+            else if (counted && want_status) meta |= P_LIST | P_STATUS_ONLY;      // a base could not be counted: exact status wanted
+            pend = Pend{(uint32_t)i, c0, ts.pos, reflen, meta, cw[0], cw[1], cw[2], cw[3], cw[4]};
         }
         F_STAMP(6);          // careful loop
     }
@@ -831,7 +861,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     store_pending(pend);
     pad_events();
     F_EPI(1);
-    if (pw_tiles && wbeg < wend) fold();
+    if (pw_tiles && n_tb) fold();
     F_EPI(2);
     __syncthreads();
 #if defined(AMP_DEV) && defined(AMP_ABL)
@@ -851,12 +881,11 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
     F_STAMP_OUT;
-    if (lane == 0) gcnt[blockIdx.x * F_WAVES + wave] = gwave;
+    if (tid == 0) gcnt[blockIdx.x] = s_gcur;
 }
 
 // Dense list of the reads the fast kernel handed over + the geometry of the general pass.  Block b places the
-// segment of fast-kernel wave b behind the totals of the waves before it (the per-wave counts are a few KB in L2);
-// read order is kept.
+// segment of fast-kernel block b behind the totals of the blocks before it (the per-block counts are a KB in L2).
 __global__ void __launch_bounds__(256)
 k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt, int reads_per_block, int64_t n_reads,
            uint32_t *__restrict__ dense, GenGeo *geo, uint32_t gen_grid, unsigned long long *ctr) {
@@ -869,9 +898,8 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
     __syncthreads();
     const uint32_t off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     const uint32_t cnt = gcnt[blockIdx.x];
-    const int per_wave = reads_per_block / F_WAVES;
-    const int64_t wbeg = (int64_t)(blockIdx.x / F_WAVES) * reads_per_block + (int64_t)(blockIdx.x % F_WAVES) * per_wave;
-    const uint32_t *src = glist + (wbeg < n_reads ? wbeg : 0);
+    const int64_t sbeg = (int64_t)blockIdx.x * reads_per_block;
+    const uint32_t *src = glist + (sbeg < n_reads ? sbeg : 0);
     for (uint32_t k = tid; k < cnt; k += 256) dense[off + k] = src[k];
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const uint32_t n_list = off + cnt;

@@ -566,12 +566,11 @@ AMP_HD void cig2_quality_clip(Cig2 &s, int32_t del) {
     s.canon();
 }
 
-// Stage 1+2 of trim_read (A:450-558) on the shape, given the two table entries
-AMP_HD void cig2_trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, Cig2 &s,
-                              int32_t left_max_end, int32_t right_min_start) {
+// Stage 1+2 of trim_read (A:450-558) on the shape, given the two table entries and the outcome of the template-length
+// test of A:452
+AMP_HD void cig2_trim_primers_isize(TrimState &st, uint32_t flag, bool isize_flag, int32_t lseq, Cig2 &s,
+                                    int32_t left_max_end, int32_t right_min_start) {
     const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
-    const int32_t at = tlen < 0 ? -tlen : tlen;
-    const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;              // A:452
     if (!(is_paired && isize_flag && is_reverse) && left_max_end >= 0) {                   // A:460
         st.flags |= AMP_TRIM_PRIMER_START;
         const int32_t del = cig2_pos_on_query(s, (int64_t)left_max_end + 1, st.pos);       // A:463
@@ -586,6 +585,11 @@ AMP_HD void cig2_trim_primers(const KParams &P, TrimState &st, uint32_t flag, in
         s.mirror();
         s.canon();
     }
+}
+AMP_HD void cig2_trim_primers(const KParams &P, TrimState &st, uint32_t flag, int32_t tlen, int32_t lseq, Cig2 &s,
+                              int32_t left_max_end, int32_t right_min_start) {
+    const int32_t at = tlen < 0 ? -tlen : tlen;
+    cig2_trim_primers_isize(st, flag, ((int64_t)at - P.max_primer_len) > (int64_t)lseq, lseq, s, left_max_end, right_min_start);   // A:452
 }
 
 // aligned-quality window of the shape (quality_window above): [lo, lo + qlen)

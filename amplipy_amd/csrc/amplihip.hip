@@ -1040,7 +1040,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_gcompact<<<(unsigned)(fg.grid * F_WAVES), 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr);
+        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr);
         HIPCHK(c, hipGetLastError());
 #ifdef AMP_DEV
         if (c->phases & 0x100u) {           // stamps of the general pass alone: the fast kernel's are dropped

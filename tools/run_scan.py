@@ -69,3 +69,13 @@ if os.environ.get("AMPLIHIP_PHASES"):
     tot = float(sum(int(x) for x in dc[8:13])) or 1.0
     print("general pass (k_tile<LIST>) stamps: tiles %d; cycles per tile P1 %.0f P2 %.0f P3 %.0f P4 %.0f tail %.0f; waves %d mean loop %.0f cyc, wait at final barrier %.0f cyc; block mean %.0f cyc"
           % (int(dc[13]), *[int(dc[8 + k]) / max(int(dc[13]), 1) for k in range(5)], int(dc[15]), int(dc[6]) / max(int(dc[15]), 1), int(dc[7]) / max(int(dc[15]), 1), int(dc[4]) / max(int(dc[15]) // 8, 1)))
+if a.check:
+    from oracle import oracle
+    hb = b.to_host()
+    ref = oracle.process(hb, G, mn, mx, mpl, 20, 4)
+    assert np.array_equal(e.counts(), ref.counts), "counts differ"
+    assert np.array_equal(out["new_pos"].cpu().numpy(), ref.trim.new_pos)
+    assert np.array_equal(out["new_ncig"].cpu().numpy().view(np.uint32), ref.trim.new_ncig)
+    order = ["ref_pos", "read", "q_from", "q_to"]
+    assert np.array_equal(np.sort(e.events(), order=order), np.sort(ref.events, order=order)), "events differ"
+    print("check ok")
