@@ -225,22 +225,24 @@ __device__ __forceinline__ bool fast_count_piece(const uint4 &q, const uint2 &sq
 
 // in-kernel phase stamps (development builds only; the numbers are shares, not durations); AMP_ABL = ablation
 // builds (parts of the kernel switched off to time the rest: results are wrong on purpose), without stamps
-#if defined(AMP_DEV) && !defined(AMP_ABL)
+#if defined(AMP_DEV) && (!defined(AMP_ABL) || defined(AMP_ABL_STAMPS))
 #define F_DBG_PARAM , uint32_t *f_dbg
 #define F_GLOB ++f_glob
+#define F_EPIW(k) do { __builtin_amdgcn_s_waitcnt(0x4F74); f_epw[0] = wall_clock64(); __builtin_amdgcn_s_waitcnt(0x0F7A); f_epw[1] = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); f_ep[k] = wall_clock64(); } while (0)
 #define F_EPI(k) do { __builtin_amdgcn_s_waitcnt(0); f_ep[k] = wall_clock64(); } while (0)
 #define F_DBG_ARG(x) , (x)
-#define F_STAMP_DECL unsigned long long f_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_prev = __builtin_amdgcn_s_memtime(); const unsigned long long f_k0 = f_prev, f_w0 = wall_clock64(); unsigned long long f_ep[3] = {0, 0, 0}; uint32_t f_glob = 0
+#define F_STAMP_DECL unsigned long long f_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f_prev = __builtin_amdgcn_s_memtime(); const unsigned long long f_k0 = f_prev, f_w0 = wall_clock64(); unsigned long long f_ep[3] = {0, 0, 0}, f_epw[2] = {0, 0}; uint32_t f_glob = 0
 #define F_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define F_STAMP_VM(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0070); unsigned long long f_n = __builtin_amdgcn_s_memtime(); f_t[k] += f_n - f_prev; f_prev = f_n; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define F_STAMP_OUT do { f_t[0] = __builtin_amdgcn_s_memtime() - f_k0; const unsigned long long f_w1 = wall_clock64(); f_t[7] = f_w1 - f_w0; if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f_t[k]); \
     atomicMax(&ctr[4], f_t[7]); atomicMax(&ctr[5], ~f_t[7]); atomicMax(&ctr[6], ~f_w0); atomicMax(&ctr[7], f_w1); \
     if (f_dbg && wave == 0) { uint32_t *f_o = f_dbg + blockIdx.x * 8; f_o[0] = (uint32_t)f_t[7]; f_o[1] = (uint32_t)f_w0; for (int k = 1; k < 7; ++k) f_o[1 + k] = (uint32_t)(f_t[k] >> 4); } \
-    if (f_dbg) { uint32_t *f_o = f_dbg + 2048 + (blockIdx.x * F_WAVES + wave) * 6; for (int k = 1; k < 7; ++k) f_o[k - 1] = (uint32_t)(f_t[k] >> 4); } } } while (0)
+    if (f_dbg) { uint32_t *f_o = f_dbg + 2048 + (blockIdx.x * F_WAVES + wave) * 6; f_o[0] = (uint32_t)((f_t[1] + f_t[2] + f_t[3] + f_t[4] + f_t[5] + f_t[6]) >> 4); f_o[1] = (uint32_t)(f_epw[0] - f_w0); f_o[2] = (uint32_t)(f_epw[1] - f_epw[0]); f_o[3] = (uint32_t)(f_ep[0] - f_epw[1]); f_o[4] = (uint32_t)(f_ep[1] - f_ep[0]); f_o[5] = (uint32_t)(f_ep[2] - f_ep[1]); } } } while (0)
 #else
 #define F_DBG_PARAM
 #define F_DBG_ARG(x)
 #define F_GLOB
+#define F_EPIW(k)
 #define F_EPI(k)
 #define F_STAMP_DECL
 #define F_STAMP(k)
@@ -676,7 +678,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                         const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op,
                                                   ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D), ((uint32_t)s.m2 << 4) | s.op,
                                                   ((uint32_t)s.c << 4) | OP_S};
-                        const bool has[5] = {s.a > 0, s.m1 > 0, s.kind != 0, s.kind != 0, s.c > 0};
+                        const bool has[5] = {s.a > 0, s.m1 > 0, s.kind != 0, s.kind != 0 && s.m2 > 0, s.c > 0};
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
                             if (has[t]) {
@@ -720,7 +722,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 // byte flags -> bits: bit b of a dword's nibble = bit 8 b of the flags
                 auto nib = [](uint32_t o) { return ((o * 0x00204081u) >> 21) & 0xFu; };
                 const uint32_t m16 = nib(o0) | (nib(o1) << 4) | (nib(o2) << 8) | (nib(o3) << 12);
-                good = (m16 >> (uint32_t)(q_ins & 7)) & ((1u << s.k) - 1u);
+                good = (m16 >> (uint32_t)(s.a + s.m1 - g_ins)) & ((1u << s.k) - 1u);       // (a clip may have taken the first inserted bases)
             }
             uint32_t runs = good & ~(good << 1);                              // first base of every run
             const unsigned long long em = __ballot(runs != 0u);
@@ -745,7 +747,8 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                         runs &= runs - 1u;
                         const int32_t je = js + __builtin_ctz(~(good >> js));
                         int32_t elo, ehi;
-                        py_slice(q0 + js - 1, q0 + je, (int32_t)lseq, elo, ehi);                   // A:738
+                        if (je == s.k && s.m2 > 0 && r2 == 0) py_slice(q0 + js, q0 + je + 1, (int32_t)lseq, elo, ehi);   // A:735-736
+                        else py_slice(q0 + js - 1, q0 + je, (int32_t)lseq, elo, ehi);              // A:738
                         int32_t ins_pos = je == s.k ? r2 : ref_end;                                // A:742 / A:739-740
                         ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                               // A:744
                         const bool inside = (uint32_t)ins_pos < G;
@@ -857,7 +860,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
         F_STAMP(6);          // careful loop
     }
-    F_EPI(0);
+    F_EPIW(0);
     store_pending(pend);
     pad_events();
     F_EPI(1);

@@ -449,9 +449,11 @@ AMP_HD void trim_quality_apply_simple(TrimState &st, bool is_reverse, int32_t i,
 
 // ---------------------------------------------------------------------------------------------
 // Closed forms for reads with at most ONE insertion or deletion:  [S a][op m1][X k][op m2][S c]
-// with X = I or D (kind 1 / 2; kind 0: no indel, k = m2 = 0).  Every clip of trim_read maps this
-// shape onto itself or onto a shape the closed forms do not cover (an insertion cut in two, an
-// indel left directly behind a soft clip): then `punt` is set and the generic code does the read.
+// with X = I or D (kind 1 / 2; kind 0: no indel, k = m2 = 0).  A clip that stops inside or right
+// in front of the indel leaves it directly behind the soft clip ([S a][X k][op m2]: m1 == 0, or
+// m2 == 0 when it came from the other end); the forms below take such shapes too.  What they do
+// not cover -- a second clip that reaches an indel which already touches a clip -- sets `punt`
+// and the generic code does the read.
 // Derived rule by rule from primer_clip / quality_clip above; tests/hostsim fuzzes them against
 // trim_read_serial (tests/test_hostsim_golden.py::test_two_segment_closed_forms).
 // ---------------------------------------------------------------------------------------------
@@ -470,7 +472,7 @@ struct Cig2 {
         int n = 0;
         if (a > 0) b.set(n++, ((uint32_t)a << 4) | OP_S);
         if (m1 > 0) b.set(n++, ((uint32_t)m1 << 4) | op);
-        if (kind) { b.set(n++, ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D)); b.set(n++, ((uint32_t)m2 << 4) | op); }
+        if (kind) { b.set(n++, ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D)); if (m2 > 0) b.set(n++, ((uint32_t)m2 << 4) | op); }
         if (c > 0) b.set(n++, ((uint32_t)c << 4) | OP_S);
         return n;
     }
@@ -527,8 +529,12 @@ AMP_HD int32_t cig2_primer_clip(Cig2 &s, int32_t del) {
         if (del < s.m1) { s.a = A + del; s.m1 -= del; return del; }
         A += s.m1; adv += s.m1; del -= s.m1; s.m1 = 0;
     }
+    if (s.kind && s.m2 == 0) { s.punt = true; return 0; }               // an indel that already touches the far clip
     if (s.kind == 1) {
-        if (del > 0 && del < s.k) { s.punt = true; return 0; }         // insertion cut in two
+        if (del > 0 && del < s.k) {                                    // insertion cut in two: its rest stays, behind the clip
+            s.a = A + del; s.m1 = 0; s.k -= del;
+            return adv;
+        }
         A += s.k; del = del >= s.k ? del - s.k : 0;                    // (del == 0: not started yet -> soft clip as well)
     } else if (s.kind == 2) {
         adv += s.k;                                                    // dropped, the start jumps over it
@@ -551,11 +557,12 @@ AMP_HD void cig2_quality_clip(Cig2 &s, int32_t del) {
         if (del < s.m1) { s.a = A + del; s.m1 -= del; return; }
         A += s.m1; del -= s.m1; s.m1 = 0;
     }
+    if (s.kind && s.m2 == 0) { s.punt = true; return; }                 // an indel that already touches the far clip
     if (s.kind == 1) {
-        if (del < s.k) { s.punt = true; return; }                      // del == 0: the insertion is copied behind the clip; else cut in two
+        if (del < s.k) { s.a = A + del; s.m1 = 0; s.k -= del; return; }  // del == 0: the insertion is copied behind the clip; else its rest
         A += s.k; del -= s.k;
     } else if (s.kind == 2) {
-        if (del == 0) { s.punt = true; return; }                       // the deletion is copied behind the clip
+        if (del == 0) { s.a = A; s.m1 = 0; return; }                   // the deletion is copied behind the clip
     }
     int32_t m = s.kind ? s.m2 : 0;
     if (m > 0 && del > 0) {
@@ -801,7 +808,8 @@ AMP_HD int cig2_indels(const KParams &P, const Cig2 &s, int32_t pos, int32_t lse
             const int32_t js = j;
             while (j < s.k && (int32_t)qual(q0 + j) >= P.min_quality) ++j;
             int32_t lo, hi, ins_pos;
-            py_slice(q0 + js - 1, q0 + j, lseq, lo, hi);                                   // A:738
+            if (j == s.k && s.m2 > 0 && r2 == 0) py_slice(q0 + js, q0 + j + 1, lseq, lo, hi);   // A:735-736: the next match base sits on reference position 0
+            else py_slice(q0 + js - 1, q0 + j, lseq, lo, hi);                              // A:738
             if (j == s.k) ins_pos = r2;                                                    // A:742
             else { ins_pos = ref_end; ++j; }                                               // A:739-740; the low base is consumed
             ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                                   // A:744

@@ -56,9 +56,9 @@ if os.environ.get("AMP_STAMPS") not in (None, "", "0") and not os.environ.get("A
     print("  phases (cycles per tile: top wait, rows+clips+issue, scan, qclip, count, careful) of the 30 fastest blocks:", [int(x) for x in ph[so[1:31]].mean(axis=0)])
     print("  ... of the 30 slowest blocks:", [int(x) for x in ph[so[-30:]].mean(axis=0)])
     raw = e.debug_blocks().reshape(-1)
-    pw = raw[2048:2048 + nw * 6].reshape(-1, 8, 6).astype(np.float64) * 16 / 2.29e3      # us per wave and phase
-    for bidx in list(so[-3:]) + list(so[1:3]):
-        print("  block %d (%.0f us): per wave us: top wait %s | rows, clips, issue %s | scan %s | quality clip %s | count %s | careful, hand-over %s" % ((bidx, bd[bidx]) + tuple([int(x) for x in pw[bidx, :, k]] for k in range(6))))
+    pw = raw[2048:2048 + nw * 6].reshape(-1, 8, 6).astype(np.float64)
+    for bidx in list(so[-4:]) + list(so[1:3]):
+        print("  block %d (%.0f us): per wave: stamped loop us %s | older stores done at %s | then the phantom tile's quality DMA %s | its base loads %s | last stores %s | last fold %s" % ((bidx, bd[bidx], [int(x * 16 / 2.29e3) for x in pw[bidx, :, 0]]) + tuple([int(x / 100) for x in pw[bidx, :, k]] for k in range(1, 6))))
     slow = np.argsort(bd)[-6:]; fast = np.argsort(bd)[:6]
     for name, idx in (("slowest", slow), ("fastest", fast)):
         print("  %s blocks:" % name, [(int(i), int(bd[i]), round(feat["reverse fraction"][i], 2), int(feat["position span"][i]), int(feat["distinct starts"][i])) for i in idx])

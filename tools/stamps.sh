@@ -5,6 +5,6 @@ set -e
 ROOT=$(pwd); D=/tmp/amp_dev_repo
 rm -rf $D; mkdir -p $D; cp -r $ROOT/amplipy_amd $ROOT/include $ROOT/tools $ROOT/oracle $D/
 cd $D
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -DAMP_DEV ${ABL:+-DAMP_ABL=$ABL} -Wno-unused-function -o amplipy_amd/libamplihip.so amplipy_amd/csrc/amplihip.hip -ldl 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -DAMP_DEV ${ABL:+-DAMP_ABL=$ABL} ${ABLS:+-DAMP_ABL_STAMPS=1} -Wno-unused-function -o amplipy_amd/libamplihip.so amplipy_amd/csrc/amplihip.hip -ldl 2>/dev/null
 T=${1:-run_scan.py}; shift || true
 AMP_STAMPS=${STAMPS-1} python3 tools/$T "$@"
