@@ -815,6 +815,9 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 p = (uint32_t)k < np ? p : np;
                 const int32_t j0 = (int32_t)(p * 16u);
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
+                // (the empty asm keeps the compiler from computing the pass-independent half of every piece in front of
+                // the pass loop, which costs eighty registers this kernel does not have)
+                asm volatile("" : "+v"(q16[k].x), "+v"(q16[k].y), "+v"(q16[k].z), "+v"(q16[k].w), "+v"(s8[k].x), "+v"(s8[k].y));
                 if (count_piece(q16[k], s8[k], j0, second ? a2 : a1, second ? b2 : b1, second ? dbase2 : dbase1)) redo |= 1u << k;
                 __builtin_amdgcn_sched_barrier(0);          // one piece at a time: interleaving them costs registers the kernel does not have
             }

@@ -75,6 +75,8 @@ struct amp_ctx {
     int64_t last_nv = 0, last_nr = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timed = false;
+    bool last_split = false;      // the last launch recorded ev1 / ev2
+    bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
     int kernel_variant = 4;       // 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
                                   // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
@@ -950,6 +952,12 @@ int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kern
     return AMP_OK;
 }
 
+int amp_set_timing(amp_ctx *c, int split) {
+    if (!c) return AMP_EINVAL;
+    c->split_timing = split != 0;
+    return AMP_OK;
+}
+
 int amp_reserve_events(amp_ctx *c, int64_t cap) {
     if (!c || cap < 0) return AMP_EINVAL;
     Guard g(c);
@@ -1035,11 +1043,11 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     } else if (variant == 4) {
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
-        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         if (fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
-        HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+        if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr);
         HIPCHK(c, hipGetLastError());
 #ifdef AMP_DEV
@@ -1074,6 +1082,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     }
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
     c->timed = true;
+    c->last_split = variant != 4 || c->split_timing;
     return AMP_OK;
 }
 
@@ -1140,7 +1149,8 @@ int amp_last_kernel_ms(amp_ctx *c, float *total_ms, float *scan_ms) {
     HIPCHK(c, hipEventSynchronize(c->ev3));
     float t = 0, s = 0;
     HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev3));
-    HIPCHK(c, hipEventElapsedTime(&s, c->ev1, c->ev2));
+    if (!c->last_split) s = t;     // (the first kernel was not timed separately)
+    else HIPCHK(c, hipEventElapsedTime(&s, c->ev1, c->ev2));
     if (total_ms) *total_ms = t;
     if (scan_ms) *scan_ms = s;
     return AMP_OK;

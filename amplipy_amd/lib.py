@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing",
 ]
 
 
@@ -120,6 +120,9 @@ class Engine:
 
     def bind_counts(self, dev_ptr):
         self._chk(self.L.amp_ctx_bind_counts(self.h, C.c_void_p(dev_ptr)), "amp_ctx_bind_counts")
+
+    def set_timing(self, split):
+        self._chk(self.L.amp_set_timing(self.h, C.c_int(1 if split else 0)), "amp_set_timing")
 
     def reserve_events(self, cap):
         self._chk(self.L.amp_reserve_events(self.h, C.c_int64(cap)), "amp_reserve_events")

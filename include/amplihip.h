@@ -184,6 +184,9 @@ int amp_sync(amp_ctx *ctx);
 /* Time spent in the kernels of the last amp_process_batch* call, measured with HIP events
  * on the ctx stream: total, and the dominant (CIGAR-scan) kernel alone. */
 int amp_last_kernel_ms(amp_ctx *ctx, float *total_ms, float *scan_ms);
+/* split != 0: also time the first (dominant) kernel of every pass on its own; the extra event leaves the GPU idle for a
+ * few microseconds behind that kernel, so it is off by default and scan_ms then repeats total_ms. */
+int amp_set_timing(amp_ctx *ctx, int split);
 
 /* ---- accumulated state ----------------------------------------------------------------- */
 int amp_get_counts(amp_ctx *ctx, uint32_t *counts /* [ref_len][AMP_NSYM] host */);

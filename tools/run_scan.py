@@ -13,7 +13,7 @@ g = synth.make_genome(); primers, amps = synth.make_artic_scheme(); G = g.size
 n = synth.reads_for_depth(a.depth)
 b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0", indel_frac=a.indel_frac); torch.cuda.synchronize()
 mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
-e = lib.Engine(G); e.set_kernel_variant(a.variant)
+e = lib.Engine(G); e.set_kernel_variant(a.variant); e.set_timing(bool(os.environ.get("AMP_SPLIT")))
 e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True); e.reserve_events(max(1 << 20, n // 4))
 out = {k: torch.zeros(sz, dtype=dt, device="cuda:0") for k, sz, dt in
        (("new_pos", n, torch.int32), ("new_ncig", n, torch.int32), ("new_cig", b.n_cig + 3 * n, torch.int32),
