@@ -72,8 +72,10 @@ struct amp_ctx {
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
     void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
-    int64_t last_nv = 0, last_nr = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    int64_t last_nv = 0, last_nr = 0, guess_v = 0, guess_r = 0;
+    bool call_pending = false;     // amp_call_compact_begin has enqueued the calling kernels; amp_call_compact_view picks them up
+    amp_call_params call_pending_params{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr;
     bool timed = false;
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
@@ -657,7 +659,8 @@ __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
 // An insertion string can only matter when the position's insertion events could out-rank
 // the best base symbol or reach the variant frequency threshold; such positions are flagged
 // AMP_CALL_INS_RELEVANT and finished by the host from the event list.
-__global__ void k_call(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ins_at,
+__global__ void __launch_bounds__(256)
+k_call(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ins_at,
                        const uint8_t *__restrict__ ref, int32_t ref_len, amp_call_params pr, amp_pos_call *__restrict__ out,
                        unsigned long long *n_relevant, uint2 *__restrict__ blk) {
     __shared__ uint32_t sv[4], sr[4];
@@ -746,12 +749,19 @@ k_call_compact(const amp_pos_call *__restrict__ pc, const uint32_t *__restrict__
         amp_var_rec v;
         v.pos = p; v.total_depth = c.total_depth; v.ref_count = c.ref_count;
         v.gt_has_ref = (c.flags & AMP_CALL_GT_HAS_REF) ? 1 : 0;
+        // ALT slot j takes the j-th ranked symbol that is flagged (static slot indices: a dynamic one puts the record
+        // into LDS, 11 KB per block, and the kernel could no longer run next to a block of the fast kernel)
+        uint32_t m = c.alt_mask & 0x3Fu;
         uint8_t na = 0;
-        for (int k = 0; k < 6; ++k) { v.alt_col[k] = 0xFF; v.alt_count[k] = 0; }
-        for (int k = 0; k < 6; ++k) {
-            if ((c.alt_mask >> k) & 1u) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (m) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1u;
                 const uint32_t col = (c.order >> (3 * k)) & 7u;
-                v.alt_col[na] = (uint8_t)col; v.alt_count[na] = counts[(size_t)p * AMP_NSYM + col]; ++na;
+                v.alt_col[j] = (uint8_t)col; v.alt_count[j] = counts[(size_t)p * AMP_NSYM + col]; ++na;
+            } else {
+                v.alt_col[j] = 0xFF; v.alt_count[j] = 0;
             }
         }
         v.n_alt = na;
@@ -872,7 +882,8 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipMemsetAsync(c->d_counts, 0, cb, c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return fail(AMP_EHIP);
+        hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
 #ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
@@ -902,6 +913,7 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
+    if (c->ev_call) (void)hipEventDestroy(c->ev_call);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -978,6 +990,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     if (c->do_trim && !c->have_primers) return AMP_ESTATE;
     const int64_t n = rd->n_reads;
     c->timed = false;
+    c->call_pending = false;       // (calls begun earlier are for the table as it was)
     if (n == 0) return AMP_OK;
     // event capacity
     if (c->do_count && !c->ev_reserved) {
@@ -1246,6 +1259,7 @@ int amp_error_reads(amp_ctx *c, int64_t *n) {  // reads with a non-zero status s
 int amp_reset(amp_ctx *c) {
     if (!c) return AMP_EINVAL;
     Guard g(c);
+    c->call_pending = false;
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_DEV_COLS * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream));
     return AMP_OK;
@@ -1307,50 +1321,83 @@ int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out,
     return AMP_OK;
 }
 
+// Layout of the compact calling image (device and pinned host copy alike)
+struct CallImage {
+    unsigned nblk; size_t off_blk, off_img, img_cons, img_vars, img_rel, img_size;
+    explicit CallImage(int32_t G) {
+        nblk = (unsigned)((G + 255) / 256);
+        off_blk = (size_t)G * sizeof(amp_pos_call);
+        off_img = (off_blk + (size_t)nblk * sizeof(uint2) + 63) & ~(size_t)63;
+        img_cons = 64; img_vars = img_cons + (((size_t)G + 63) & ~(size_t)63);
+        img_rel = img_vars + (size_t)G * sizeof(amp_var_rec); img_size = img_rel + (size_t)G * 4;
+    }
+};
+
+// Enqueues the calling kernels and the copy of the image's likely-used prefix on the ctx stream; does not wait.
+static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
+    const int32_t G = c->ref_len;
+    // device buffer: [per-position calls][block counts] | output image [totals 64 B][consensus][records][relevant positions]
+    // The output image has the same layout in the pinned host buffer, so its used prefix travels in ONE copy.
+    const CallImage L(G);
+    HIPCHK(c, c->call_buf.ensure(L.off_img + L.img_size + 64));
+    uint8_t *base = c->call_buf.as<uint8_t>(), *img = base + L.off_img;
+    amp_pos_call *d_pc = (amp_pos_call *)base;
+    if (c->h_pin_cap < L.img_size) {
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr; c->h_pin_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_pin, L.img_size, hipHostMallocDefault));
+        c->h_pin_cap = L.img_size;
+    }
+    k_call<<<L.nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + L.off_blk));
+    HIPCHK(c, hipGetLastError());
+    k_call_compact<<<L.nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + L.off_blk), (int8_t *)(img + L.img_cons),
+                                                  (amp_var_rec *)(img + L.img_vars), (int32_t *)(img + L.img_rel), (unsigned long long *)img);
+    HIPCHK(c, hipGetLastError());
+    uint8_t *hp = (uint8_t *)c->h_pin;
+    // as many records as the previous call produced (plus a margin); more copies only when this call produced more
+    c->guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
+    c->guess_r = c->last_nr ? std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64) : 0;
+    HIPCHK(c, hipMemcpyAsync(hp, img, L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+    if (c->guess_r) HIPCHK(c, hipMemcpyAsync(hp + L.img_rel, img + L.img_rel, (size_t)c->guess_r * 4, hipMemcpyDeviceToHost, c->stream));
+    return AMP_OK;
+}
+
+int amp_call_compact_begin(amp_ctx *c, const amp_call_params *pr) {
+    if (!c || !pr) return AMP_EINVAL;
+    if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
+    Guard g(c);
+    const int rc = call_compact_enqueue(c, pr);
+    if (rc != AMP_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_call, c->stream));     // the view waits for THIS point, not for what is enqueued behind it
+    c->call_pending = true; c->call_pending_params = *pr;
+    return AMP_OK;
+}
+
 int amp_call_compact_view(amp_ctx *c, const amp_call_params *pr, amp_call_view *view) {
     if (!c || !pr || !view) return AMP_EINVAL;
     if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
     Guard g(c);
     const int32_t G = c->ref_len;
-    // device buffer: [per-position calls][block counts] | output image [totals 64 B][consensus][records][relevant positions]
-    // The output image has the same layout in the pinned host buffer, so its used prefix travels in ONE copy.
-    const unsigned nblk = (unsigned)((G + 255) / 256);
-    const size_t off_blk = (size_t)G * sizeof(amp_pos_call);
-    const size_t off_img = (off_blk + (size_t)nblk * sizeof(uint2) + 63) & ~(size_t)63;
-    const size_t img_cons = 64, img_vars = img_cons + (((size_t)G + 63) & ~(size_t)63);
-    const size_t img_rel = img_vars + (size_t)G * sizeof(amp_var_rec), img_size = img_rel + (size_t)G * 4;
-    HIPCHK(c, c->call_buf.ensure(off_img + img_size + 64));
-    uint8_t *base = c->call_buf.as<uint8_t>(), *img = base + off_img;
-    amp_pos_call *d_pc = (amp_pos_call *)base;
-    k_call<<<nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + off_blk));
-    HIPCHK(c, hipGetLastError());
-    k_call_compact<<<nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + off_blk), (int8_t *)(img + img_cons),
-                                                (amp_var_rec *)(img + img_vars), (int32_t *)(img + img_rel), (unsigned long long *)img);
-    HIPCHK(c, hipGetLastError());
-    if (c->h_pin_cap < img_size) {
-        if (c->h_pin) (void)hipHostFree(c->h_pin);
-        c->h_pin = nullptr; c->h_pin_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_pin, img_size, hipHostMallocDefault));
-        c->h_pin_cap = img_size;
-    }
+    const CallImage L(G);
+    // work enqueued by amp_call_compact_begin with the same parameters is picked up here; anything else starts now
+    const bool begun = c->call_pending && memcmp(&c->call_pending_params, pr, sizeof(*pr)) == 0;
+    c->call_pending = false;
+    if (!begun) { const int rc = call_compact_enqueue(c, pr); if (rc != AMP_OK) return rc; }
+    uint8_t *img = c->call_buf.as<uint8_t>() + L.off_img;
     uint8_t *hp = (uint8_t *)c->h_pin;
     const unsigned long long *h_nn = (const unsigned long long *)hp;
-    const int8_t *h_cons = (const int8_t *)(hp + img_cons);
-    amp_var_rec *h_vars = (amp_var_rec *)(hp + img_vars);
-    int32_t *h_rel = (int32_t *)(hp + img_rel);
-    // as many records as the previous call produced (plus a margin); more copies only when this call produced more
-    const int64_t guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
-    const int64_t guess_r = c->last_nr ? std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64) : 0;
-    HIPCHK(c, hipMemcpyAsync(hp, img, img_vars + (size_t)guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-    if (guess_r) HIPCHK(c, hipMemcpyAsync(h_rel, img + img_rel, (size_t)guess_r * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int8_t *h_cons = (const int8_t *)(hp + L.img_cons);
+    amp_var_rec *h_vars = (amp_var_rec *)(hp + L.img_vars);
+    int32_t *h_rel = (int32_t *)(hp + L.img_rel);
+    if (begun) HIPCHK(c, hipEventSynchronize(c->ev_call));
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
     const int64_t nv = (int64_t)h_nn[0], nr = (int64_t)h_nn[1];
     c->last_nv = nv; c->last_nr = nr;
-    if (nv > guess_v || nr > guess_r) {
-        if (nv > guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + guess_v, img + img_vars + (size_t)guess_v * sizeof(amp_var_rec),
-                                                   (size_t)(nv - guess_v) * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-        if (nr > guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + guess_r, img + img_rel + (size_t)guess_r * 4, (size_t)(nr - guess_r) * 4,
-                                                   hipMemcpyDeviceToHost, c->stream));
+    if (nv > c->guess_v || nr > c->guess_r) {
+        if (nv > c->guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + c->guess_v, img + L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec),
+                                                      (size_t)(nv - c->guess_v) * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
+        if (nr > c->guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + c->guess_r, img + L.img_rel + (size_t)c->guess_r * 4, (size_t)(nr - c->guess_r) * 4,
+                                                      hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     *view = amp_call_view{h_cons, h_vars, h_rel, nv, nr};

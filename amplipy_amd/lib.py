@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin",
 ]
 
 
@@ -208,6 +208,10 @@ class Engine:
         self._chk(self.L.amp_call_positions(self.h, C.byref(params), C.c_void_p(abi.ptr(out)), C.byref(nr)),
                   "amp_call_positions")
         return out, int(nr.value)
+
+    def call_compact_begin(self, params):
+        """Enqueue the calling kernels now; the next call_compact with the same parameters only waits for them."""
+        self._chk(self.L.amp_call_compact_begin(self.h, C.byref(params)), "amp_call_compact_begin")
 
     def call_compact(self, params):
         """amp_call_compact_view -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R]).  The arrays

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
     ap.add_argument("--variant", type=int, default=4)
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (each has its own stream, engine and outputs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
     args = ap.parse_args()
@@ -110,11 +111,16 @@ def main():
     rd = batch.struct()
     cp = calling.call_params(10, 0.0, 1, 0.03, True, True)
 
+    # ONE HIP stream for the GPU work of every step: the GPU runs reads(k), calls(k), reads(k+1), ... strictly in that
+    # order (with a stream per step the small calling kernels of step k had to wait for a CU behind the blocks of the
+    # next step's reads, which fill every CU), and the host assembles step k's records while reads(k+1) run
+    work_stream = torch.cuda.Stream(device=dev)
+
     class Slot:
-        """One in-flight step: its own HIP stream, engine (device table, event list, scratch) and outputs."""
+        """One in-flight step: its own engine (device table, event list, scratch, pinned result image) and outputs."""
 
         def __init__(self, b=batch):
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = work_stream
             self.eng = eng = lib.Engine(G, device=local_rank)
             eng.set_kernel_variant(args.variant)
             eng.set_stream(self.stream.cuda_stream)
@@ -147,9 +153,9 @@ def main():
             return calling.tallies_from_events(pairs, positions)
 
     # Steps are software-pipelined `depth` deep: the kernels of step k run while the host assembles the
-    # records of step k-1 (and, N > 1, while RCCL all-reduces its table).  Every step is complete -
+    # records of step k-1.  Every step is complete -
     # kernels, reduce, calls, records, consensus string - before the timed region ends.
-    depth = 1 if args.no_pipeline else 2
+    depth = 1 if args.no_pipeline else max(1, args.in_flight)
     slots = [Slot() for _ in range(depth)]
     pass_ms, fast_ms = [], []
     last = {}
@@ -162,6 +168,8 @@ def main():
             if dist is not None:
                 # ONE collective per step: afterwards every rank holds the whole job's table and makes the same calls
                 parallel.allreduce_table(dist, sl.table)
+            # the calling kernels go in right behind: queued in front of the next step's reads, not behind them
+            sl.eng.call_compact_begin(cp)
 
     def finish(k):
         sl = slots[k % depth]

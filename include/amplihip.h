@@ -287,6 +287,10 @@ typedef struct amp_call_view {
     int64_t n_vars, n_relevant;
 } amp_call_view;
 int amp_call_compact_view(amp_ctx *ctx, const amp_call_params *params, amp_call_view *out);
+/* Enqueue the work of amp_call_compact_view on the ctx stream without waiting (right behind amp_process_batch_device,
+ * say): a following amp_call_compact_view with the same parameters only waits for it and hands the views out.  Lets a
+ * caller with several contexts in flight keep the calling kernels of one step in front of the next step's reads. */
+int amp_call_compact_begin(amp_ctx *ctx, const amp_call_params *params);
 /* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
  * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host. */
 int amp_event_strings(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int64_t n_events,
