@@ -315,16 +315,17 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 }
 
 // Second-pass treatment of a read the tile kernel could not hold (more CIGAR ops than its LDS
-// column): serial trim with both CIGAR buffers in LDS columns, then
+// column): serial trim with both CIGAR buffers in LDS columns -- or, for CIGARs of more than D_MAXOPS - 3 ops
+// (Nanopore-like reads), ping-pong between the read's output slot and the scratch slot in global memory --, then
 //   * regular trimmed CIGAR (clips at the ends, body of M/=/X/I/D/N): deletions / insertion events by
 //     the skip-ahead walk on this lane; the match bases are left to the block's waves (count_match_coop)
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
 constexpr int D_MAXOPS = 20;
-template <class Sink>
-__device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
-                                      const EventBuf &eb, bool status_only, LdsCig256 &cur, LdsCig256 &tmp, uint32_t c0, int n,
-                                      int &n_final, int32_t &pos_final) {
+template <class CB, class Sink>
+__device__ bool process_read_full(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
+                                  const EventBuf &eb, bool status_only, CB &cur, CB &tmp, uint32_t c0, int n,
+                                  int &n_final, int32_t &pos_final) {
     uint32_t *const home = out.new_cig + (size_t)c0 + 3 * (size_t)i;
     for (int k = 0; k < n; ++k) cur.set(k, rd.cig[c0 + k]);
     const int32_t lseq = (int32_t)rd.lseq[i];
@@ -333,7 +334,7 @@ __device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd,
     const bool have_qual = lseq > 0 && qual[0] != 0xFF;
     TrimState st{rd.pos[i], n, 0u, 0};
     if (P.do_trim) trim_read_serial(P, st, rd.flag[i], rd.tlen[i], lseq, qual, have_qual, cur, tmp);
-    if (!st.err)
+    if (!st.err && !is_home(cur, home))
         for (int k = 0; k < st.n; ++k) home[k] = cur.get(k);
     int err = st.err;
     bool coop = false;
@@ -372,30 +373,37 @@ __device__ bool process_read_full_lds(const KParams &P, const amp_dev_reads &rd,
 // A base that cannot be counted (code outside ACGTN, position past the table) makes the group's
 // first lane run the exact walk for the read's status, like the tile kernel's status-only deferral.
 constexpr int D_GROUP = 16;
-template <class Sink>
+template <class CB, class Sink>
 __device__ void count_match_coop(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
-                                 const EventBuf &eb, const LdsCig256 &cig, int n, int32_t pos, int lane) {
+                                 const EventBuf &eb, const CB &cig, int n, int32_t pos, int lane) {
     const int32_t lseq = (int32_t)rd.lseq[i];
     const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
     const uint8_t *qual = rd.qual + boff;
     const uint32_t G = (uint32_t)P.ref_len;
     int32_t q = 0, r = pos;
     bool bad = false;
-    for (int k = 0; k < n; ++k) {
-        const uint32_t v = cig.get(k), op = v & 15u;
-        const int32_t len = (int32_t)(v >> 4);
-        if (is_match_op(op)) {
-            for (int32_t j = lane; j < len; j += D_GROUP) {
-                if ((int32_t)qual[q + j] < P.min_quality) continue;
-                const uint32_t col = code_to_col(base_code(rd.seq, boff, q + j));
-                if (col == 0xFFu || (uint32_t)(r + j) >= G) bad = true;
-                else sink.add(r + j, col);
-            }
-            q += len; r += len;
-        } else if (op == OP_I || op == OP_S) q += len;
-        else if (op == OP_D || op == OP_N) r += len;
+    // the ops come D_GROUP at a time, one per lane, and are handed round with shuffles: a CIGAR that lives in global
+    // memory (tens of ops) costs a round trip per sixteen ops instead of one per op
+    const int lane0 = (int)(threadIdx.x & 63u) & ~(D_GROUP - 1);
+    for (int k0 = 0; k0 < n; k0 += D_GROUP) {
+        const uint32_t mine = k0 + lane < n ? cig.get(k0 + lane) : 0u;
+        const int kn = n - k0 < D_GROUP ? n - k0 : D_GROUP;
+        for (int k = 0; k < kn; ++k) {
+            const uint32_t v = (uint32_t)__shfl((int)mine, lane0 + k), op = v & 15u;
+            const int32_t len = (int32_t)(v >> 4);
+            if (is_match_op(op)) {
+                for (int32_t j = lane; j < len; j += D_GROUP) {
+                    if ((int32_t)qual[q + j] < P.min_quality) continue;
+                    const uint32_t col = code_to_col(base_code(rd.seq, boff, q + j));
+                    if (col == 0xFFu || (uint32_t)(r + j) >= G) bad = true;
+                    else sink.add(r + j, col);
+                }
+                q += len; r += len;
+            } else if (op == OP_I || op == OP_S) q += len;
+            else if (op == OP_D || op == OP_N) r += len;
+        }
     }
-    const uint64_t gmask = ((1ull << D_GROUP) - 1ull) << ((threadIdx.x & 63u) & ~(uint32_t)(D_GROUP - 1));
+    const uint64_t gmask = ((1ull << D_GROUP) - 1ull) << lane0;
     if ((__ballot(bad) & gmask) && lane == 0) {
         NullSink ns;
         const int err = count_read_walk(P, cig, n, pos, lseq, ReadBytesCached{rd.seq, boff, qual}, true, ns);
@@ -572,11 +580,12 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
                 if (n + 3 <= D_MAXOPS) {
                     LdsCig256 cur{(lds_u32 *)s_cig + threadIdx.x}, tmp{(lds_u32 *)s_cig + D_MAXOPS * 256 + threadIdx.x};
                     int nf; int32_t pf;
-                    if (process_read_full_lds(P, rd, i, out, sink, eb, status_only, cur, tmp, c0, n, nf, pf)) {
+                    if (process_read_full(P, rd, i, out, sink, eb, status_only, cur, tmp, c0, n, nf, pf)) {
+                        // cooperative entry: read, final ops | column of the lane that trimmed it << 22 | buffer B << 30, start
                         const uint32_t slot = atomicAdd(&s_ncoop, 1u) - done;
                         const uint32_t in_b = cur.p != (lds_u32 *)s_cig + threadIdx.x;
                         s_coop[slot * 3] = (uint32_t)i;
-                        s_coop[slot * 3 + 1] = (uint32_t)nf | (in_b << 8) | (threadIdx.x << 16);
+                        s_coop[slot * 3 + 1] = (uint32_t)nf | (threadIdx.x << 22) | (in_b << 30);
                         s_coop[slot * 3 + 2] = (uint32_t)pf;
                     }
                 } else {
@@ -602,8 +611,16 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
                     if (bound) base0 = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)bound);
                     const bool fits = bound && (long long)(base0 + bound) <= eb.cap;
                     SliceSink ss{sink, eb.ev + (size_t)shard * (size_t)eb.cap + base0, fits ? bound : 0u, 0u};
-                    process_read_body(P, rd, i, out, ss, eb, status_only, CigBuf<1>{out.new_cig + slot}, CigBuf<1>{scratch + slot},
-                                      out.new_cig + slot, c0, n);
+                    // the trim runs on this lane; a regular result leaves only its indels here (skip-ahead walk) and
+                    // hands the match bases to a group of lanes, which reads the final CIGAR from the output slot
+                    CigBuf<1> cur{out.new_cig + slot}, tmp{scratch + slot};
+                    int nf; int32_t pf;
+                    if (process_read_full(P, rd, i, out, ss, eb, status_only, cur, tmp, c0, n, nf, pf)) {
+                        const uint32_t cslot = atomicAdd(&s_ncoop, 1u) - done;
+                        s_coop[cslot * 3] = (uint32_t)i;
+                        s_coop[cslot * 3 + 1] = ((uint32_t)nf & 0x3FFFFFu) | (1u << 31);      // bit 31: the CIGAR is in global memory
+                        s_coop[cslot * 3 + 2] = (uint32_t)pf;
+                    }
                     for (uint32_t k = ss.used; k < ss.cap; ++k) ss.slice[k] = amp_ins_event{-1, 0u, 0, 0};
                 }
             }
@@ -614,8 +631,13 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
             const int64_t i = (int64_t)s_coop[c * 3];
             const uint32_t w = s_coop[c * 3 + 1];
             WinSink sink{(lds_u32 *)s_win, base, counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
-            const LdsCig256 cig{(lds_u32 *)s_cig + ((w >> 8) & 1u) * (D_MAXOPS * 256) + (w >> 16)};
-            count_match_coop(P, rd, i, out, sink, eb, cig, (int)(w & 0xFFu), (int32_t)s_coop[c * 3 + 2], (int)(threadIdx.x % D_GROUP));
+            if (w >> 31) {
+                const CigBuf<1> cig{out.new_cig + (size_t)rd.cig_off32[i] + 3 * (size_t)i};
+                count_match_coop(P, rd, i, out, sink, eb, cig, (int)(w & 0x3FFFFFu), (int32_t)s_coop[c * 3 + 2], (int)(threadIdx.x % D_GROUP));
+            } else {
+                const LdsCig256 cig{(lds_u32 *)s_cig + ((w >> 30) & 1u) * (D_MAXOPS * 256) + ((w >> 22) & 0xFFu)};
+                count_match_coop(P, rd, i, out, sink, eb, cig, (int)(w & 0x3FFFFFu), (int32_t)s_coop[c * 3 + 2], (int)(threadIdx.x % D_GROUP));
+            }
         }
         done += ncoop;
         flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
