@@ -5,6 +5,8 @@
     update_base_counts(symbol_counts_at_ref_pos, s, min_quality)                            AmpliPy.py:690, :915
     alleles_from_counts(symbol_counts) -> (total, [(count, freq, symbol), ...])             AmpliPy.py:756, :925
     find_overlapping_primers(ref_genome_len, primers, primer_pos_offset)                    AmpliPy.py:174
+    get_pos_on_query(cigar, ref_pos, ref_start) / get_pos_on_ref(cigar, query_pos, ref_start) / fix_cigar(cigar)
+                                                                                            AmpliPy.py:389, :363, :415
 
 A call per read through an FFI costs far more than the work (the drop-in boundary is the
 batch), so this module is for code and tests written against the reference's function signatures, not for
@@ -82,3 +84,22 @@ def alleles_from_counts(symbol_counts):
     """Total count and the alleles with a non-zero count as (count, frequency, symbol), largest tuple first."""
     total = sum(symbol_counts.values())
     return total, sorted(((c, c / total, k) for k, c in symbol_counts.items() if c != 0), reverse=True)
+
+
+def _helpers(cigar, ref_start, ref_pos=0, query_pos=0):
+    e = _engine(1)
+    oq, orf, fixed, st = e.coordinate_helpers([[(int(op), int(l)) for op, l in cigar]], [ref_start], [ref_pos], [query_pos])
+    _raise(st[0])
+    return int(oq[0]), int(orf[0]), fixed[0]
+
+
+def get_pos_on_query(cigar, ref_pos, ref_start):
+    return _helpers(cigar, ref_start, ref_pos=ref_pos)[0]
+
+
+def get_pos_on_ref(cigar, query_pos, ref_start):
+    return _helpers(cigar, ref_start, query_pos=query_pos)[1]
+
+
+def fix_cigar(cigar):
+    return [tuple(x) for x in _helpers(cigar, 0)[2]]

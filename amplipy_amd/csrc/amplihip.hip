@@ -1440,6 +1440,60 @@ int amp_call_compact(amp_ctx *c, const amp_call_params *pr, int8_t *consensus, a
     return AMP_OK;
 }
 
+// The reference's coordinate helpers on the device, one lane per case: get_pos_on_query (A:389-412), get_pos_on_ref
+// (A:363-386) and fix_cigar (A:415-423) -- the very device functions the kernels use (amp_read.hpp), driven directly.
+__global__ void __launch_bounds__(256)
+k_coordinate_helpers(int64_t n, const uint32_t *__restrict__ cig_off, uint32_t *cig, const int32_t *__restrict__ ref_start,
+                     const int32_t *__restrict__ ref_pos, const int32_t *__restrict__ query_pos, int32_t *out_q, int32_t *out_r,
+                     uint32_t *fixed, uint32_t *fixed_n, uint8_t *status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c0 = cig_off[i];
+    const int nops = (int)(cig_off[i + 1] - c0);
+    const CigBuf<1> c{cig + c0};
+    int e1 = 0, e2 = 0;
+    out_q[i] = pos_on_query(c, nops, ref_pos[i], ref_start[i], e1);
+    out_r[i] = pos_on_ref(c, nops, query_pos[i], ref_start[i], e2);
+    Emitter<CigBuf<1>> e{CigBuf<1>{fixed + c0}};
+    for (int k = 0; k < nops; ++k) { const uint32_t v = c.get(k); e.push(v & 15u, v >> 4); }
+    fixed_n[i] = (uint32_t)e.finish();
+    status[i] = (uint8_t)(e1 ? e1 : e2);
+}
+
+int amp_coordinate_helpers(amp_ctx *c, int64_t n, const uint32_t *cig_off, const uint32_t *cig, const int32_t *ref_start,
+                           const int32_t *ref_pos, const int32_t *query_pos, int32_t *pos_on_query_out, int32_t *pos_on_ref_out,
+                           uint32_t *fixed_cig, uint32_t *fixed_n, uint8_t *status) {
+    if (!c || n < 0) return AMP_EINVAL;
+    if (n == 0) return AMP_OK;
+    if (!cig_off || !ref_start || !ref_pos || !query_pos || !pos_on_query_out || !pos_on_ref_out || !fixed_cig || !fixed_n || !status)
+        return AMP_EINVAL;
+    const size_t nc = cig_off[n];
+    if (nc && !cig) return AMP_EINVAL;
+    Guard g(c);
+    // one scratch image: offsets | ops | starts | ref positions | query positions | the two results | fixed ops | their counts | status
+    const size_t words = ((size_t)n + 1) + nc + 3 * (size_t)n + 2 * (size_t)n + nc + (size_t)n + ((size_t)n + 3) / 4 + 16;
+    HIPCHK(c, c->call_buf.ensure(words * 4));
+    uint32_t *d = c->call_buf.as<uint32_t>();
+    uint32_t *d_off = d, *d_cig = d_off + n + 1;
+    int32_t *d_rs = (int32_t *)(d_cig + nc), *d_rp = d_rs + n, *d_qp = d_rp + n, *d_oq = d_qp + n, *d_or = d_oq + n;
+    uint32_t *d_fx = (uint32_t *)(d_or + n), *d_fn = d_fx + nc;
+    uint8_t *d_st = (uint8_t *)(d_fn + n);
+    HIPCHK(c, hipMemcpyAsync(d_off, cig_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (nc) HIPCHK(c, hipMemcpyAsync(d_cig, cig, nc * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rs, ref_start, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rp, ref_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_qp, query_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    k_coordinate_helpers<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(n, d_off, d_cig, d_rs, d_rp, d_qp, d_oq, d_or, d_fx, d_fn, d_st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(pos_on_query_out, d_oq, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pos_on_ref_out, d_or, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (nc) HIPCHK(c, hipMemcpyAsync(fixed_cig, d_fx, nc * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fixed_n, d_fn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMP_OK;
+}
+
 int amp_event_strings(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base, int64_t n_ev, const amp_ins_event *ev,
                       const uint64_t *off, uint8_t *text) {
     if (!c || !rd || n_ev < 0 || (n_ev && (!ev || !off || !text))) return AMP_EINVAL;

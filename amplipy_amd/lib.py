@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers",
 ]
 
 
@@ -208,6 +208,23 @@ class Engine:
         self._chk(self.L.amp_call_positions(self.h, C.byref(params), C.c_void_p(abi.ptr(out)), C.byref(nr)),
                   "amp_call_positions")
         return out, int(nr.value)
+
+    def coordinate_helpers(self, cigars, ref_start, ref_pos, query_pos):
+        """get_pos_on_query / get_pos_on_ref / fix_cigar (AmpliPy.py:363-423) for a list of CIGARs [(op, len), ...] on the
+        device -> (pos_on_query int32[n], pos_on_ref int32[n], [fixed cigar tuples], status uint8[n])."""
+        n = len(cigars)
+        off = np.zeros(n + 1, np.uint32)
+        off[1:] = np.cumsum([len(c) for c in cigars])
+        words = np.array([(int(l) << 4) | int(op) for c in cigars for op, l in c], np.uint32)
+        rs, rp, qp = (np.ascontiguousarray(x, np.int32) for x in (ref_start, ref_pos, query_pos))
+        oq, orf = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        fx, fn, st = np.zeros(max(words.size, 1), np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self._chk(self.L.amp_coordinate_helpers(self.h, C.c_int64(n), C.c_void_p(abi.ptr(off)), C.c_void_p(abi.ptr(words) if words.size else None),
+                                                C.c_void_p(abi.ptr(rs)), C.c_void_p(abi.ptr(rp)), C.c_void_p(abi.ptr(qp)),
+                                                C.c_void_p(abi.ptr(oq)), C.c_void_p(abi.ptr(orf)), C.c_void_p(abi.ptr(fx)),
+                                                C.c_void_p(abi.ptr(fn)), C.c_void_p(abi.ptr(st))), "amp_coordinate_helpers")
+        fixed = [[(int(w & 15), int(w >> 4)) for w in fx[int(off[i]):int(off[i]) + int(fn[i])]] for i in range(n)]
+        return oq, orf, fixed, st
 
     def call_compact_begin(self, params):
         """Enqueue the calling kernels now; the next call_compact with the same parameters only waits for them."""

@@ -202,6 +202,15 @@ int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);
 int amp_reset(amp_ctx *ctx); /* zero the count table and drop recorded events */
 /* Number of reads with a non-zero amp_read_status since the last amp_reset. */
 int amp_error_reads(amp_ctx *ctx, int64_t *n);
+/* The reference's coordinate helpers for n CIGARs at once, computed on the device by the functions the kernels use:
+ *   pos_on_query_out[i] = get_pos_on_query(cigar_i, ref_pos[i], ref_start[i])        (AmpliPy.py:389-412)
+ *   pos_on_ref_out[i]   = get_pos_on_ref(cigar_i, query_pos[i], ref_start[i])        (AmpliPy.py:363-386)
+ *   fixed_cig[cig_off[i] ..] / fixed_n[i] = fix_cigar(cigar_i)                       (AmpliPy.py:415-423)
+ * cig_off[n + 1] / cig as in amp_reads (32-bit offsets, BAM words); status[i] = amp_read_status (an op code >= 9 makes
+ * the reference's table look-up fail).  Host pointers; synchronous. */
+int amp_coordinate_helpers(amp_ctx *ctx, int64_t n, const uint32_t *cig_off, const uint32_t *cig, const int32_t *ref_start,
+                           const int32_t *ref_pos, const int32_t *query_pos, int32_t *pos_on_query_out, int32_t *pos_on_ref_out,
+                           uint32_t *fixed_cig, uint32_t *fixed_n, uint8_t *status);
 /* Development aid: the 16 raw device counters ([0] events, [1] event bound, [2] error reads,
  * [3] deferred reads, [8..13] per-phase cycle sums when AMPLIHIP_PHASES has bit 0x100). */
 int amp_debug_counters(amp_ctx *ctx, uint64_t *out16);

@@ -414,6 +414,31 @@ def test_function_level_seams_replay_the_named_cases():
     assert tot == 10 and [a[2] for a in alleles] == ["T", "AT", "A", "-"] and alleles[0][1] == 0.3
 
 
+def test_coordinate_helpers_on_the_device():
+    """Rows a2-a4 of SURVEY.md section 8 on their own: the 1,500 reference-derived vectors of tests/golden/helpers.json
+    (get_pos_on_query A:389-412, get_pos_on_ref A:363-386, fix_cigar A:415-423) replayed through the DEVICE functions
+    the kernels use (amp_coordinate_helpers), in one batch and through the reference's own signatures (compat)."""
+    from amplipy_amd import compat, lib
+    cases = H.load_json("helpers.json")["cases"]
+    eng = lib.Engine(1000)
+    cigs = [[tuple(x) for x in c["cigar"]] for c in cases]
+    start = [c["start"] for c in cases]
+    oq, orf, fixed, st = eng.coordinate_helpers(cigs, start, [c["start"] + c["x"] for c in cases], [c["x"] for c in cases])
+    assert not st.any()
+    assert oq.tolist() == [c["pos_on_query"] for c in cases]
+    assert orf.tolist() == [c["pos_on_ref"] for c in cases]
+    assert fixed == [[tuple(x) for x in c["fix_cigar"]] for c in cases]
+    eng.close()
+    for c in cases[:25]:
+        cig = [tuple(x) for x in c["cigar"]]
+        assert compat.get_pos_on_query(cig, c["start"] + c["x"], c["start"]) == c["pos_on_query"]
+        assert compat.get_pos_on_ref(cig, c["x"], c["start"]) == c["pos_on_ref"]
+        assert compat.fix_cigar(cig) == [tuple(x) for x in c["fix_cigar"]]
+    # an op code outside the reference's tables raises there (KeyError on CONSUME_*): reported as a status here
+    _, _, _, st = lib.Engine(10).coordinate_helpers([[(0, 5), (9, 2)]], [0], [7], [6])
+    assert st[0] != 0
+
+
 @pytest.mark.parametrize("seed", list(range(3000, 3012)))
 def test_randomised_parameters_and_read_shapes(runner, seed):
     """A slice of tools/fuzz_gpu.py: random min_quality / window / primer offset, three families of reads
