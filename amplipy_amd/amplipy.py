@@ -263,17 +263,19 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         batch = ReadBatch.from_segments([r.to_segment() for r in pending])
         res = eng.process(batch, read_base=read_base)
         bad = np.nonzero(res.status)[0]
-        if len(bad):                      # the reference dies on the first such read with an uncaught exception
-            _raise_for_status(res.status[bad[0]])
+        good_until = int(bad[0]) if len(bad) else len(pending)
         if run_trim and writer is not None:
-            for k, r in enumerate(pending):
+            for k, r in enumerate(pending[:good_until]):
                 fl = int(res.trim_flags[k])
                 if int(res.ref_len[k]) >= min_length and ((fl & 3) or include_no_primer):      # AmpliPy.py:910
                     writer.write(r, pos=int(res.new_pos[k]), cigar=res.cigar_ops(k))
+        if len(bad):                      # the reference dies on the first such read with an uncaught exception,
+            _raise_for_status(res.status[bad[0]])      # having written every read in front of it (A:907-911)
         if do_count:
-            ev = eng.events()
-            new = ev[ev["read"] >= read_base] if read_base else ev
-            ins_store.add(batch, new, read_base)
+            # this batch's events only: the list is drained batch by batch (read ids are 32-bit and relative to
+            # read_base modulo 2^32, which a batch never spans)
+            ev = eng.drain_events()
+            ins_store.add(batch, ev, read_base & 0xFFFFFFFF)
         read_base += batch.n
         del pending[:]
 
@@ -313,19 +315,20 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                     continue
                 res = eng.process(batch, read_base=read_base)
                 bad = np.nonzero(res.status)[0]
-                if len(bad):
-                    _raise_for_status(res.status[bad[0]])
                 if wq is not None:
                     if werr:
                         raise werr[0]
                     keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
+                    if len(bad):
+                        keep[int(bad[0]):] = False          # the reads in front of the failing one are still written (A:907-911)
                     slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
                     # src_index is a view of the decoder's buffers, which the next decode overwrites
                     wq.put((batch.src_index.copy(), keep, res.new_pos, res.new_ncig, slot_off, res.new_cig))
+                if len(bad):
+                    _raise_for_status(res.status[bad[0]])
                 if do_count:
-                    ev = eng.events()
-                    new = ev[ev["read"] >= read_base] if read_base else ev
-                    ins_store.add(batch, new, read_base)
+                    ev = eng.drain_events()
+                    ins_store.add(batch, ev, read_base & 0xFFFFFFFF)
                 read_base += batch.n
         finally:
             if wq is not None:

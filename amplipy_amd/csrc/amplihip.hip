@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <new>
 #include <vector>
 
@@ -384,12 +385,15 @@ __device__ void count_match_coop(const KParams &P, const amp_dev_reads &rd, int6
     bool bad = false;
     // the ops come D_GROUP at a time, one per lane, and are handed round with shuffles: a CIGAR that lives in global
     // memory (tens of ops) costs a round trip per sixteen ops instead of one per op
+    // (a CIGAR in an LDS column is simply read op by op)
+    constexpr bool in_lds = std::is_same<CB, LdsCig256>::value;
     const int lane0 = (int)(threadIdx.x & 63u) & ~(D_GROUP - 1);
     for (int k0 = 0; k0 < n; k0 += D_GROUP) {
-        const uint32_t mine = k0 + lane < n ? cig.get(k0 + lane) : 0u;
+        uint32_t mine = 0u;
+        if (!in_lds) mine = k0 + lane < n ? cig.get(k0 + lane) : 0u;
         const int kn = n - k0 < D_GROUP ? n - k0 : D_GROUP;
         for (int k = 0; k < kn; ++k) {
-            const uint32_t v = (uint32_t)__shfl((int)mine, lane0 + k), op = v & 15u;
+            const uint32_t v = in_lds ? cig.get(k0 + k) : (uint32_t)__shfl((int)mine, lane0 + k), op = v & 15u;
             const int32_t len = (int32_t)(v >> 4);
             if (is_match_op(op)) {
                 for (int32_t j = lane; j < len; j += D_GROUP) {
@@ -1238,6 +1242,16 @@ int amp_get_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap) 
             if (buf[k].ref_pos >= 0) { if (w != k) buf[w] = buf[k]; ++w; }
         *n = w;
     }
+    return AMP_OK;
+}
+
+int amp_drain_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap) {
+    // amp_get_ins_events, then the list starts over (the per-position tally stays): a run of many batches reads every
+    // event once instead of the whole accumulated list after each batch, and the device list stays one batch long
+    const int rc = amp_get_ins_events(c, n, buf, cap);
+    if (rc != AMP_OK || !buf) return rc;
+    Guard g(c);
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr[16], 0, EV_SHARDS * sizeof(unsigned long long), c->stream));
     return AMP_OK;
 }
 

@@ -45,7 +45,7 @@ class EventStore:
     def add(self, batch, events, read_base=0):
         if events.size == 0:
             return
-        i = events["read"].astype(np.int64) - int(read_base)
+        i = (events["read"].astype(np.int64) - int(read_base)) & 0xFFFFFFFF      # read ids are 32-bit: relative to read_base modulo 2^32
         start = batch.seq_off[i].astype(np.int64) + events["q_from"].astype(np.int64)
         length = np.maximum(events["q_to"].astype(np.int64) - events["q_from"].astype(np.int64), 0)
         total = int(length.sum())

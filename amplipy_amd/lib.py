@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events",
 ]
 
 
@@ -173,6 +173,14 @@ class Engine:
             self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)),
                       "amp_get_ins_events")
         return ev[:int(n.value)]          # the size query counts slots; a few may have been reserved and left unused
+
+    def drain_events(self):
+        """The events recorded since the last drain (or reset); the device list is empty afterwards."""
+        n = C.c_int64(0)
+        self._chk(self.L.amp_get_ins_events(self.h, C.byref(n), None, C.c_int64(0)), "amp_get_ins_events")
+        ev = np.zeros(max(int(n.value), 1), abi.INS_EVENT_DTYPE)
+        self._chk(self.L.amp_drain_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)), "amp_drain_ins_events")
+        return ev[:int(n.value)]
 
     def debug_blocks(self):
         out = np.zeros((4096, 4), np.uint32); nb = C.c_int(0)

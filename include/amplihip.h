@@ -195,6 +195,9 @@ int amp_add_counts(amp_ctx *ctx, const uint32_t *counts /* host, added element-w
  * CIGARs reserve a slice and may leave part of it unused).  buf != NULL (cap >= that bound): the events
  * are copied and *n = their exact number. */
 int amp_get_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
+/* The same, after which the event list is empty again (the per-position tally of amp_get_counts stays): for runs of many
+ * batches, where the text of the events is taken batch by batch.  Call with buf == NULL first for the size, like above. */
+int amp_drain_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
 void *amp_counts_device_ptr(amp_ctx *ctx);
 /* Sum the device tables (counts + insertion tally) over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
  * (root < 0: all ranks).  comm == NULL is a no-op (single GPU). */
@@ -220,12 +223,14 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
 /* Pre-size the insertion-event buffer.  Without it every amp_process_batch* call first runs
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
  * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short.
- * `cap` is per list shard (there are 8); size it for the events of a batch plus 64 slots for
- * every 64 reads' worth of slack: waves reserve list slots 64 at a time and leave some unused. */
+ * `cap` is per list shard (there are 8, and any of them may receive most of a batch's events); size it for twice the
+ * events of a batch plus 64 slots per wave of the fast kernel (8 per CU): waves reserve list slots 64 at a time and
+ * leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 2 (default) = fused tile kernel; 1 = one-lane-per-read kernels and 3 = the same work cut into three
- * kernels (k_trim, k_scan, k_tile<SPLIT>), both kept for on-GPU A/B checks (all three give identical
- * results).  Also settable with the environment variable AMPLIHIP_KERNEL. */
+/* 4 (default) = the fast kernel (closed-form trim + pileup of reads with one match op or one insertion / deletion, every byte
+ * loaded once) followed by the general pass over the reads it hands over; 2 = the fused tile kernel over every read; 1 =
+ * one-lane-per-read kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks
+ * (all four give identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
 
 /* ---- calling: alleles_from_counts (AmpliPy.py:756-771) + the loop AmpliPy.py:917-952 --------

@@ -1,0 +1,77 @@
+"""BASELINE config 5 at its full size: mixed 75-300 bp reads with long soft clips and indel-heavy CIGARs at 50k x depth
+(about 8.0 M reads), one launch, checked against the C oracle (development aid; needs a GPU).
+The batch is the 40,000-read pool of synth.make_mixed_segments gathered 200 times with numpy, every copy shifted by 0..7
+positions and the whole sorted again, so packing takes seconds.
+usage: time_config5.py [replication] [--no-check]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amplipy_amd import lib, synth
+from amplipy_amd.batch import ReadBatch
+
+
+def gather_rows(b, idx):
+    """The rows idx of batch b as a new batch (variable-length CIGARs / bases gathered with repeat + cumsum)."""
+    def spans(off, unit_pad=1):
+        ln = (off[1:] - off[:-1]).astype(np.int64)[idx]
+        new_off = np.zeros(idx.size + 1, np.int64); np.cumsum(ln, out=new_off[1:])
+        src = np.repeat(off[:-1].astype(np.int64)[idx] - new_off[:-1], ln) + np.arange(int(new_off[-1]), dtype=np.int64)
+        return new_off, src
+    co, csrc = spans(b.cig_off)
+    so, ssrc = spans(b.seq_off)
+    seq_nib = np.empty(b.seq.size * 2, np.uint8); seq_nib[0::2] = b.seq >> 4; seq_nib[1::2] = b.seq & 15
+    nib = seq_nib[ssrc]
+    return ReadBatch(b.pos[idx], b.flag[idx], b.tlen[idx], b.lseq[idx], co.astype(np.uint64), b.cig[csrc], so.astype(np.uint64),
+                     ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8), b.qual[ssrc])
+
+
+rep = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200
+g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+pr = [(s, e) for s, e, _ in primers]
+pool = ReadBatch.from_segments(sorted(synth.make_mixed_segments(g, amps, 40000, seed=3), key=lambda s: s.reference_start))
+t = time.time()
+# every pool read rep times, each copy shifted by 0..7 positions (seeded) and the batch sorted again: copies of different
+# reads interleave like the reads of a real pile (rep identical reads in a row would make every tile homogeneous)
+rng = np.random.default_rng(5)
+idx = np.repeat(np.arange(pool.n, dtype=np.int64), rep)
+jit = rng.integers(0, 8, idx.size).astype(np.int32)
+order = np.argsort(pool.pos[idx].astype(np.int64) + jit, kind="stable")
+idx, jit = idx[order], jit[order]
+b = gather_rows(pool, idx)
+span = np.zeros(pool.n, np.int64)
+for i in range(pool.n):
+    w = pool.cig[int(pool.cig_off[i]):int(pool.cig_off[i + 1])]
+    span[i] = int(((w >> 4) * np.isin(w & 15, (0, 2, 3, 7, 8))).sum())
+ok = pool.pos[idx].astype(np.int64) + jit + span[idx] < g.size          # (a shifted copy must still end inside the reference)
+b.pos[:] = pool.pos[idx] + np.where(ok, jit, 0).astype(np.int32)
+assert np.all(np.diff(b.pos.astype(np.int64)) >= -7)
+nops = np.diff(b.cig_off.astype(np.int64))
+print("packed %d reads in %.1f s: %.1f M bases, mean length %.0f, mean CIGAR ops %.1f (max %d), %.1f %% with an indel or more than one op"
+      % (b.n, time.time() - t, b.total_bases() / 1e6, b.lseq.mean(), nops.mean(), nops.max(), 100.0 * (nops > 1).mean()))
+mn, mx, mpl = lib.find_overlapping_primers(g.size, pr, 0)
+e = lib.Engine(g.size); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True); e.reserve_events(b.n // 2)
+for it in range(3):
+    e.reset(); res = e.process(b); tot, scan = e.last_kernel_ms()
+    dc = e.debug_counters()
+    print("launch %d: all kernels %.3f ms = %.3f ms per 1 M reads -> %.1f M reads/s, %.1f G bases/s; general-pass reads %d, of which %d left to the second pass"
+          % (it, tot, tot / (b.n / 1e6), b.n / tot / 1e3, b.total_bases() / tot / 1e6, int(dc[7]), int(dc[3])))
+if "--no-check" not in sys.argv:
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    counts = e.counts()
+    cores = 16
+    cuts = [b.n * k // cores for k in range(cores + 1)]
+    def shard(k):
+        sb = b.slice(cuts[k], cuts[k + 1])
+        r = oracle.process(sb, g.size, mn, mx, mpl, 20, 4, read_base=cuts[k])
+        assert np.array_equal(r.trim.new_pos, res.new_pos[cuts[k]:cuts[k + 1]]) and np.array_equal(r.trim.new_ncig, res.new_ncig[cuts[k]:cuts[k + 1]])
+        assert np.array_equal(r.trim.status, res.status[cuts[k]:cuts[k + 1]])
+        return r.counts, r.events.size
+    t = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        parts = list(ex.map(shard, range(cores)))
+    ref = sum(p[0].astype(np.uint64) for p in parts).astype(np.uint32)
+    assert np.array_equal(ref, counts), "count table differs from the oracle"
+    assert sum(p[1] for p in parts) == e.events().size, "number of insertion events differs from the oracle"
+    print("check ok: count table, trimmed positions, op counts, statuses and the number of insertion events equal the C oracle's (%.1f s on %d threads)"
+          % (time.time() - t, cores))
