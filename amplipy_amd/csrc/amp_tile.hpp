@@ -924,6 +924,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     if (n_err) atomicAdd(&ctr[2], n_err);
     if (tid == 0) {
         dcnt[blockIdx.x] = L.dcount; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = L.dcount2;
+        if (L.dcount2) atomicOr(&ctr[24], 1ull);        // tells the heavy pass that it has something to do at all (sticky until amp_reset)
         // (no per-block atomic on a shared counter here: thousands of blocks on one address serialise;
         //  amp_debug_counters sums the per-block list counts instead)
     }

@@ -74,9 +74,11 @@ struct amp_ctx {
     DBuf call_buf;
     void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
     int64_t last_nv = 0, last_nr = 0, guess_v = 0, guess_r = 0;
+    bool copy_busy = false;        // a copy of the calling image may still be in flight on copy_stream (ev_call says when it is done)
     bool call_pending = false;     // amp_call_compact_begin has enqueued the calling kernels; amp_call_compact_view picks them up
     amp_call_params call_pending_params{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr, ev_img = nullptr;
+    hipStream_t copy_stream = nullptr;    // the calling image travels to the host beside the work stream, not in it
     bool timed = false;
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
@@ -448,48 +450,6 @@ __device__ int process_read_indels(const KParams &P, const amp_dev_reads &rd, in
     return count_regular_skip(P, cig, n, pos, lseq, qs, qe, qf, sink);
 }
 
-// Second pass of variant 2, light half: reads whose match bases the tile kernel counted and that only
-// have deletions / insertion events left; one per lane off the front of the block's list segment.
-__global__ void __launch_bounds__(256)
-k_deferred_light(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
-                 EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg,
-                 const GenGeo *geo, long long dcnt_stride) {
-    if (geo) { tiles_per_block = (long long)geo->tpb; n_seg = (long long)geo->n_seg; }   // general pass of variant 4
-    __shared__ uint32_t s_cig[T_MAXOPS * 256];
-    __shared__ uint32_t s_ev[4 * D_EVCAP];
-    __shared__ uint32_t s_nev;
-    __shared__ unsigned long long s_evbase;
-    // half a block (128 lanes) per list segment, D_LSEG segments per block (a segment rarely fills a whole block)
-    constexpr int D_LSEG = 2, D_LLANES = 256 / D_LSEG;
-    const int64_t sb = (int64_t)blockIdx.x * D_LSEG + (threadIdx.x / D_LLANES);
-    const uint32_t lane = threadIdx.x % D_LLANES;
-    const uint32_t cnt = sb < n_seg ? dcnt[sb] : 0u;
-    uint32_t cmax = 0;
-    for (int w = 0; w < D_LSEG; ++w) {
-        const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w;
-        const uint32_t c2 = s2 < n_seg ? dcnt[s2] : 0u;
-        cmax = c2 > cmax ? c2 : cmax;
-    }
-    if (threadIdx.x == 0) {      // tell the heavy pass whether it has anything to do at all (ctr[24], sticky until amp_reset)
-        uint32_t hv = 0;
-        for (int w = 0; w < D_LSEG; ++w) { const int64_t s2 = (int64_t)blockIdx.x * D_LSEG + w; if (s2 < n_seg) hv |= dcnt[5 * dcnt_stride + 64 + s2]; }
-        if (hv) atomicOr(&eb.ctr[24], 1ull);
-    }
-    if (cmax == 0) return;
-    const uint32_t *seg = dlist + (size_t)sb * (size_t)tiles_per_block * TILE;
-    if (threadIdx.x == 0) s_nev = 0;
-    __syncthreads();
-    for (uint32_t k0 = 0; k0 < cmax; k0 += D_LLANES) {
-        const uint32_t k = k0 + lane;
-        if (k < cnt) {
-            const int64_t i = (int64_t)(seg[k] & DEFER_INDEX_MASK);
-            StageSink sink{counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
-            if (process_read_indels(P, rd, i, out, sink, (lds_u32 *)s_cig + threadIdx.x))
-                process_read_serial(P, rd, i, read_base, out, scratch, counts, eb, true);   // exact status
-        }
-        flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
-    }
-}
 
 // Heavy half, off the back of the segment: reads the tile kernel could not take at all (more CIGAR ops
 // than its LDS column, unusual CIGAR, no room in the tile's segment table) and reads that need
@@ -666,7 +626,7 @@ k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
                  EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg,
                  const GenGeo *geo, long long dcnt_stride, const uint32_t *rlist) {
     __shared__ HeavyLds L;
-    if (__hip_atomic_load(&eb.ctr[24], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // set by k_deferred_light
+    if (__hip_atomic_load(&eb.ctr[24], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // set by the tile kernel
     if (geo) { tiles_per_block = (long long)geo->tpb; n_seg = (long long)geo->n_seg; }
     heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
     __syncthreads();
@@ -909,7 +869,9 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming) != hipSuccess) return fail(AMP_EHIP);
+        hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_img, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
 #ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
@@ -940,6 +902,8 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->ev_call) (void)hipEventDestroy(c->ev_call);
+    if (c->ev_img) (void)hipEventDestroy(c->ev_img);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1099,9 +1063,8 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         k_tile<false, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
                                                                                     gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
         HIPCHK(c, hipGetLastError());
-        k_deferred_light<<<(unsigned)((gen_grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo,
-                                                                               (long long)tg.grid);
-        HIPCHK(c, hipGetLastError());
+        // (the tile kernel does the indels of regular reads itself and raises the heavy pass's flag: k_deferred_light, round 1's
+        // second-pass kernel for them, is no longer launched)
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
             P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo, (long long)tg.grid, gdense);
         HIPCHK(c, hipGetLastError());
@@ -1112,9 +1075,6 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
                      : tile_launch(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, c->n_cu, c->phases, c->stream);
         if (rc != 0) { snprintf(c->err, sizeof(c->err), "tile kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return AMP_EHIP; }
         HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_deferred_light<<<(unsigned)((tg.grid + 1) / 2), 256, 0, c->stream>>>(P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt,
-                                                                               (long long)tg.tpb, (long long)tg.grid, nullptr, (long long)tg.grid);
-        HIPCHK(c, hipGetLastError());
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
             P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, (long long)tg.tpb, (long long)tg.grid, nullptr, (long long)tg.grid, nullptr);
         HIPCHK(c, hipGetLastError());
@@ -1384,6 +1344,8 @@ static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
         HIPCHK(c, hipHostMalloc(&c->h_pin, L.img_size, hipHostMallocDefault));
         c->h_pin_cap = L.img_size;
     }
+    // (the image of this ctx's previous call must have left the device before it is overwritten)
+    if (c->copy_busy) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_call, 0));
     k_call<<<L.nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + L.off_blk));
     HIPCHK(c, hipGetLastError());
     k_call_compact<<<L.nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + L.off_blk), (int8_t *)(img + L.img_cons),
@@ -1393,8 +1355,14 @@ static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
     // as many records as the previous call produced (plus a margin); more copies only when this call produced more
     c->guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
     c->guess_r = c->last_nr ? std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64) : 0;
-    HIPCHK(c, hipMemcpyAsync(hp, img, L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-    if (c->guess_r) HIPCHK(c, hipMemcpyAsync(hp + L.img_rel, img + L.img_rel, (size_t)c->guess_r * 4, hipMemcpyDeviceToHost, c->stream));
+    // The copy runs on its own stream behind the kernels: in the work stream it would hold up whatever the caller enqueues
+    // next (the following batch) for the ~20 us half a megabyte takes over PCIe.
+    HIPCHK(c, hipEventRecord(c->ev_img, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_img, 0));
+    HIPCHK(c, hipMemcpyAsync(hp, img, L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->copy_stream));
+    if (c->guess_r) HIPCHK(c, hipMemcpyAsync(hp + L.img_rel, img + L.img_rel, (size_t)c->guess_r * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_call, c->copy_stream));     // "the image has arrived"
+    c->copy_busy = true;
     return AMP_OK;
 }
 
@@ -1404,8 +1372,7 @@ int amp_call_compact_begin(amp_ctx *c, const amp_call_params *pr) {
     Guard g(c);
     const int rc = call_compact_enqueue(c, pr);
     if (rc != AMP_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_call, c->stream));     // the view waits for THIS point, not for what is enqueued behind it
-    c->call_pending = true; c->call_pending_params = *pr;
+    c->call_pending = true; c->call_pending_params = *pr;     // (the view waits for the copy's event, not for what is enqueued behind it)
     return AMP_OK;
 }
 
@@ -1425,8 +1392,8 @@ int amp_call_compact_view(amp_ctx *c, const amp_call_params *pr, amp_call_view *
     const int8_t *h_cons = (const int8_t *)(hp + L.img_cons);
     amp_var_rec *h_vars = (amp_var_rec *)(hp + L.img_vars);
     int32_t *h_rel = (int32_t *)(hp + L.img_rel);
-    if (begun) HIPCHK(c, hipEventSynchronize(c->ev_call));
-    else HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_call));
+    c->copy_busy = false;
     const int64_t nv = (int64_t)h_nn[0], nr = (int64_t)h_nn[1];
     c->last_nv = nv; c->last_nr = nr;
     if (nv > c->guess_v || nr > c->guess_r) {
