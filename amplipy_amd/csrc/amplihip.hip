@@ -633,6 +633,18 @@ k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, ui
     heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
 }
 
+// amp_reset: zeroes the device table and the counters
+__global__ void __launch_bounds__(256)
+k_reset(uint32_t *a, size_t na, uint32_t *b, size_t nb) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = i0 + k;
+        if (i < na) a[i] = 0u;
+        else if (i - na < nb) b[i - na] = 0u;
+    }
+}
+
 __global__ void k_add_u32(uint32_t *dst, const uint32_t *src, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -1256,8 +1268,10 @@ int amp_reset(amp_ctx *c) {
     if (!c) return AMP_EINVAL;
     Guard g(c);
     c->call_pending = false;
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->ref_len * AMP_DEV_COLS * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream));
+    // one small kernel for the table and the counters (two hipMemsetAsync calls are three fill kernels of 5 us each)
+    const size_t words = (size_t)c->ref_len * AMP_DEV_COLS;
+    k_reset<<<(unsigned)((words + 64 + 1023) / 1024), 256, 0, c->stream>>>(c->d_counts, words, (uint32_t *)c->d_ctr, 64);
+    HIPCHK(c, hipGetLastError());
     return AMP_OK;
 }
 
