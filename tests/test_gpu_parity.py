@@ -414,6 +414,58 @@ def test_function_level_seams_replay_the_named_cases():
     assert tot == 10 and [a[2] for a in alleles] == ["T", "AT", "A", "-"] and alleles[0][1] == 0.3
 
 
+@pytest.mark.parametrize("seed,mq,w,off", [(41, 20, 4, 0), (42, 10, 1, 2), (43, 30, 8, 1), (44, 0, 3, 0), (45, 25, 6, 3), (46, 20, 2, 0)])
+def test_short_reads_with_one_indel(runner, seed, mq, w, off):
+    """The shapes the fast kernel does in closed form (amp_fast.hpp / Cig2 in amp_read.hpp): reads of up to 152 bases with one
+    match op or two around ONE insertion / deletion, dense primer tables so that the clips of A:450-558 and A:589-686 often
+    stop inside or right in front of the indel, low-quality runs inside insertions (several events per insertion), reads
+    at reference position 0 (A:735-736), at the end of the reference, with N calls of good quality, and piles further
+    apart than the kernel's packed window.  Trim results, count table and insertion events against the oracle."""
+    from amplipy_amd.segment import Segment
+    rng = np.random.default_rng(seed)
+    G = 6000
+    primers = sorted((int(a), int(a) + int(rng.integers(18, 32))) for a in rng.integers(0, G - 40, 60))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, off)
+    segs = []
+    starts = np.sort(np.concatenate([rng.integers(0, G - 200, 40), [0, 0, 1, G - 160]]))
+    for s0 in starts:
+        for _ in range(int(rng.integers(20, 140))):                      # a pile of reads per start, jittered
+            kind = int(rng.integers(0, 3))
+            m1 = int(rng.integers(1, 100)); k = int(rng.integers(1, 9)) if kind else 0; m2 = int(rng.integers(1, 60)) if kind else 0
+            L = m1 + (k if kind == 1 else 0) + m2
+            if L > 152:
+                continue
+            op = 7 if rng.random() < 0.1 else 0
+            cig = [(op, m1)] + ([(kind, k), (op, m2)] if kind else [])
+            pos = int(min(max(s0 + rng.integers(-3, 4), 0), G - (m1 + m2 + (k if kind == 2 else 0)) - 1))
+            q = rng.choice([37, 25, 11, 2], L, p=[0.7, 0.15, 0.1, 0.05]).astype(np.int64)
+            t = int(rng.integers(0, 25))
+            if rng.random() < 0.3:
+                q[:t] = 2
+            elif rng.random() < 0.4:
+                q[L - t:] = 2
+            seq = "".join(rng.choice(list("ACGTN"), L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+            flag = int(rng.choice([0, 16, 99, 147, 83, 163]))
+            segs.append(Segment(flag=flag, reference_start=pos, cigar=cig, template_length=int(rng.choice([0, 300, -300, 90])),
+                                query_sequence=seq, query_qualities=q.tolist()))
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, mq, w)
+    d = runner.process(b, G, mn, mx, mpl, mq, w)
+    assert_same(a, d, b, check_counts=False)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    assert ok.size > 0.9 * b.n
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    for do_trim in (True, False):
+        a = oracle.process(good, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        keep = np.nonzero(a.trim.status == 0)[0]
+        good2 = good if keep.size == good.n else ReadBatch.from_segments([segs[ok[i]] for i in keep])
+        a = oracle.process(good2, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        d = runner.process(good2, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        assert_same(a, d, good2)
+        assert a.events.size > 50
+
+
 def test_coordinate_helpers_on_the_device():
     """Rows a2-a4 of SURVEY.md section 8 on their own: the 1,500 reference-derived vectors of tests/golden/helpers.json
     (get_pos_on_query A:389-412, get_pos_on_ref A:363-386, fix_cigar A:415-423) replayed through the DEVICE functions
