@@ -784,61 +784,69 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (!regular || e1 || e2) { defer_full = true; nseg = 0; }
             else counted = true;
         }
-        // segments: one per match op, allotted by a wave scan; a read that does not fit is deferred
-        uint32_t total_seg;
-        uint32_t sb = wave_excl_scan((uint32_t)nseg, lane, total_seg);
-        if (counted && sb + (uint32_t)nseg > (uint32_t)T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }
-        uint32_t nch4 = 0;
-        if (counted) {
-            int32_t q = 0, r = ts.pos;
-            uint32_t sidx = sb;
-            for (int k = 0; k < ts.n; ++k) {
-                uint32_t v = cur.get(k), op = v & 15u;
-                int32_t len = (int32_t)(v >> 4);
-                if (is_match_op(op)) {
-                    if (len > 0) {
-                        seg[G_M * T_SEGCAP + sidx] = (uint32_t)q | ((uint32_t)(q + len) << 16);
-                        seg[G_R0 * T_SEGCAP + sidx] = (uint32_t)r;
-                        seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
-                        nch4 += (uint32_t)(((q + len + 7) >> 3) - (q >> 3));
-                    } else {
-                        seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_R0 * T_SEGCAP + sidx] = 0u;
-                        seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
-                    }
-                    ++sidx;
-                    q += len; r += len;
-                } else if (op == OP_I || op == OP_S) q += len;
-                else if (op == OP_D || op == OP_N) r += len;
-            }
-        }
-        const bool defer_indels = counted && !plain;   // deletions and insertion events: compacted second pass
-        if (!(phases & 4u)) nch4 = 0;
-        uint32_t total4;
-        const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
-
-        AMP_STAMP(2);
-        bs_c4 += total4;
-        // =================================== P4: lane = chunk ===================================
-        for (uint32_t base = 0; base < total4; base += T_MAPCAP) {
-            wave_sync();
-            if (counted) {   // read lanes publish chunk -> segment for this round
-                uint32_t cpos = cb4;
-                for (int sgi = 0; sgi < nseg; ++sgi) {
-                    const uint32_t mm = seg[G_M * T_SEGCAP + sb + sgi];
-                    const uint32_t m0 = mm & 0xFFFFu, m1 = mm >> 16;
-                    const uint32_t nc = m1 > m0 ? ((m1 + 7) >> 3) - (m0 >> 3) : 0u;
-                    seg[G_RC * T_SEGCAP + sb + sgi] = (uint32_t)lane | (cpos << 8);
-                    uint32_t a = cpos > base ? cpos : base, b = cpos + nc < base + T_MAPCAP ? cpos + nc : base + T_MAPCAP;
-                    for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)(sb + sgi);
-                    cpos += nc;
+        // segments: one per match op, allotted by a wave scan.  A tile whose reads have more match ops than the table holds
+        // is counted in several passes (a read that did not fit used to go to the second pass, whole: on a list of
+        // indel-heavy reads that was one read in twenty-five, and the second pass took as long as this kernel)
+        if (counted && nseg > T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }      // (one read alone overflows it)
+        const bool defer_indels = counted && !plain;   // deletions and insertion events: the in-tile walk below
+        bool seg_todo = counted;
+        for (;;) {
+            uint32_t total_seg;
+            const uint32_t sb = wave_excl_scan(seg_todo ? (uint32_t)nseg : 0u, lane, total_seg);
+            const bool now = seg_todo && sb + (uint32_t)nseg <= (uint32_t)T_SEGCAP;            // (the first lane left always fits)
+            uint32_t nch4 = 0;
+            if (now) {
+                int32_t q = 0, r = ts.pos;
+                uint32_t sidx = sb;
+                for (int k = 0; k < ts.n; ++k) {
+                    uint32_t v = cur.get(k), op = v & 15u;
+                    int32_t len = (int32_t)(v >> 4);
+                    if (is_match_op(op)) {
+                        if (len > 0) {
+                            seg[G_M * T_SEGCAP + sidx] = (uint32_t)q | ((uint32_t)(q + len) << 16);
+                            seg[G_R0 * T_SEGCAP + sidx] = (uint32_t)r;
+                            seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
+                            nch4 += (uint32_t)(((q + len + 7) >> 3) - (q >> 3));
+                        } else {
+                            seg[G_M * T_SEGCAP + sidx] = 0u; seg[G_R0 * T_SEGCAP + sidx] = 0u;
+                            seg[G_RC * T_SEGCAP + sidx] = (uint32_t)lane;
+                        }
+                        ++sidx;
+                        q += len; r += len;
+                    } else if (op == OP_I || op == OP_S) q += len;
+                    else if (op == OP_D || op == OP_N) r += len;
                 }
             }
+            if (!(phases & 4u)) nch4 = 0;
+            uint32_t total4;
+            const uint32_t cb4 = wave_excl_scan(nch4, lane, total4);
+
+            AMP_STAMP(2);
+            bs_c4 += total4;
+            // =================================== P4: lane = chunk ===================================
+            for (uint32_t base = 0; base < total4; base += T_MAPCAP) {
+                wave_sync();
+                if (now) {   // read lanes publish chunk -> segment for this round
+                    uint32_t cpos = cb4;
+                    for (int sgi = 0; sgi < nseg; ++sgi) {
+                        const uint32_t mm = seg[G_M * T_SEGCAP + sb + sgi];
+                        const uint32_t m0 = mm & 0xFFFFu, m1 = mm >> 16;
+                        const uint32_t nc = m1 > m0 ? ((m1 + 7) >> 3) - (m0 >> 3) : 0u;
+                        seg[G_RC * T_SEGCAP + sb + sgi] = (uint32_t)lane | (cpos << 8);
+                        uint32_t a = cpos > base ? cpos : base, b = cpos + nc < base + T_MAPCAP ? cpos + nc : base + T_MAPCAP;
+                        for (uint32_t c = a; c < b; ++c) cmap[c - base] = (uint8_t)(sb + sgi);
+                        cpos += nc;
+                    }
+                }
+                wave_sync();
+                const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
+                p4_round(env, lane, lim, base);
+            }
             wave_sync();
-            const uint32_t lim = total4 - base < (uint32_t)T_MAPCAP ? total4 - base : (uint32_t)T_MAPCAP;
-            p4_round(env, lane, lim, base);
+            AMP_STAMP(3);
+            seg_todo = seg_todo && !now;
+            if (!__ballot(seg_todo)) break;
         }
-        wave_sync();
-        AMP_STAMP(3);
 
         // ---- deletions, reference skips and insertion events of regular reads (A:714-715, A:730-748), lane = read:
         // the skip-ahead walk over the final CIGAR, which is still in the lane's LDS column; '-' goes through the
