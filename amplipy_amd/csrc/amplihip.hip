@@ -170,7 +170,7 @@ struct DevSink {
 // so their counts are privatised in a block-wide LDS window (device-scope atomics on distinct
 // addresses run at ~23 G/s chip-wide on MI355X: they, not the walk, bound a lane-per-read pass).
 // Positions outside the window go straight to the global table.
-constexpr uint32_t D_WIN = 512;
+constexpr uint32_t D_WIN = 1024;            // positions of the second pass's LDS window (with 512 the 400-base reads of a segment fell outside it half the time: global atomics)
 constexpr uint32_t D_PLANES = AMP_NSYM + 1;   // six symbols + the insertion-event tally
 constexpr uint32_t D_EVCAP = 512;             // events staged per round (the rest go out one by one)
 struct WinSink {

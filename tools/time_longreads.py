@@ -37,6 +37,12 @@ e = lib.Engine(G); e.set_primers(mn, mx, mpl); e.set_params(10, 4, True, True)
 for it in range(3):
     e.reset(); e.process(b, want_trim=False); tot, scan = e.last_kernel_ms()
     print("iter %d: kernels %.3f ms (tile %.3f) -> %.1f M reads/s, %.2f G bases/s; errors %d" % (it, tot, scan, b.n / tot / 1e3, b.total_bases() / tot / 1e6, e.error_reads()))
+for name, trim, count in (("trim only", True, False), ("count only", False, True)):
+    e.set_params(10, 4, trim, count)
+    for it in range(2):
+        e.reset(); e.process(b, want_trim=False); tot, scan = e.last_kernel_ms()
+    print("%s: kernels %.3f ms" % (name, tot))
+e.set_params(10, 4, True, True)
 base = ReadBatch.from_segments(pool)
 e.reset(); e.process(base, want_trim=False); c1 = e.counts()
 e.reset(); e.process(b, want_trim=False); cN = e.counts()
