@@ -357,7 +357,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         return HdrP{h.pos, (h.lseq > 0xFFFFu ? 0xFFFFu : h.lseq) | ((h.flag & 1u) << 16) | (((h.flag >> 4) & 1u) << 17) | ((isz ? 1u : 0u) << 18) | ((n > 7u ? 7u : n) << 19),
                     h.c0, h.o8};
     };
-    struct Cg { uint32_t w0, w1, w2; };
+    struct Cg { uint32_t w[5]; };
     struct Geo { uint32_t np, phi, row, Tq; int ntake; bool solo, taken, fastq; };
     struct Tabs { int32_t L, R; };
     struct Bytes { uint2 raws[F_STAGE / 1024]; };
@@ -371,12 +371,14 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
         return h;
     };
-    // the first three CIGAR words (lanes past the wave's reads have c1 == c0)
+    // the first five CIGAR words (lanes past the block's reads have none)
     auto load_cig = [&](const HdrP &h) {
-        Cg c{0u, 0u, 0u};
+        Cg c{{0u, 0u, 0u, 0u, 0u}};
         const uint32_t nops = h.nops();
-        if (nops >= 1u) c.w0 = rd.cig[h.c0];
-        if (nops == 3u) { c.w1 = rd.cig[h.c0 + 1]; c.w2 = rd.cig[h.c0 + 2]; }
+        if (nops >= 1u && nops <= 5u) {
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; ++k) c.w[k] = rd.cig[h.c0 + (k < nops ? k : 0u)];        // (words past the read's own repeat its first)
+        }
         return c;
     };
     // the tile's run: the bytes of its leading reads, at most F_STAGE quality bytes (64 reads of up to 152 bases always
@@ -405,15 +407,16 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         return g;
     };
     // The shape of a read the fast path takes: one match op ("150M"), or two around ONE insertion / deletion
-    // ("70M2I78M", "70M3D80M"); refspan = its reference length (A:451 looks the right table up at its last position)
+    // ("70M2I78M", "70M3D80M"), with or without soft clips at the ends ("12S138M", "5S70M2I61M12S"); refspan = its
+    // reference length (A:451 looks the right table up at its last position)
     auto shape_of = [&](const HdrP &h, const Cg &c, bool fastq) {
         Shape r;
         r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
         const int nops = (int)h.nops();
-        r.ok = fastq && (nops == 1 || nops == 3) && cig2_from_words(nops, c.w0, c.w1, c.w2, (int32_t)h.lseq(), r.s);
+        r.ok = fastq && nops >= 1 && nops <= 5 && cig2_from_words5(nops, c.w, (int32_t)h.lseq(), r.s);
         if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
         if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
-        r.refspan = r.s.kind ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : (int32_t)h.lseq();
+        r.refspan = r.ok ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : 1;               // (m2 = 0 without an indel; soft clips cover no reference)
         return r;
     };
     // the two primer-table entries of A:450-451
@@ -563,7 +566,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const bool rev = (flag & 0x10u) != 0;
         // query index of the first inserted base / of the base behind the deletion, and of the second match segment:
         // no clip moves them while the indel survives
-        const int32_t q_ins = s.kind ? s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
+        const int32_t q_ins = s.kind ? s.a + s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
         TrimState ts{pos, 1, 0u, 0};
         if (shaped && P.do_trim) {
             if (!in_ref) ts.err = AMP_RS_INDEX_REF;

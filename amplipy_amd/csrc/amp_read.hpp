@@ -513,6 +513,41 @@ AMP_HD bool cig2_from_words(int n, uint32_t w0, uint32_t w1, uint32_t w2, int32_
     return s.query_len() == lseq;
 }
 
+// the same for input CIGARs that carry soft clips at their ends (aligners clip adapters and primers): up to five ops
+// [S a][op m1]([I|D k][op m2])[S c]
+AMP_HD bool cig2_from_words5(int n, const uint32_t (&w)[5], int32_t lseq, Cig2 &s) {
+    // (no indexing by a run-time value: on the GPU that would put the five words into scratch memory)
+    if (n < 1 || n > 5 || lseq <= 0) return false;
+    s.a = 0; s.c = 0; s.k = 0; s.m2 = 0; s.kind = 0; s.punt = false;
+    const bool lead = (w[0] & 15u) == OP_S;
+    if (lead) s.a = (int32_t)(w[0] >> 4);
+    const uint32_t v0 = lead ? w[1] : w[0], v1 = lead ? w[2] : w[1], v2 = lead ? w[3] : w[2], v3 = lead ? w[4] : w[3];
+    const int m = n - (lead ? 1 : 0);                      // ops behind the leading clip: M | M S | M X M | M X M S
+    if (lead && s.a <= 0) return false;
+    if (m < 1 || m > 4) return false;
+    const uint32_t o0 = v0 & 15u;
+    if (!(o0 == OP_M || o0 == OP_EQ || o0 == OP_X)) return false;
+    s.op = o0; s.m1 = (int32_t)(v0 >> 4);
+    if (s.m1 <= 0) return false;
+    uint32_t tail = 0;                                     // the trailing clip's word, if any
+    bool has_tail = false;
+    if (m >= 3) {
+        const uint32_t o1 = v1 & 15u;
+        if (!(o1 == OP_I || o1 == OP_D) || (v2 & 15u) != o0) return false;
+        s.kind = o1 == OP_I ? 1 : 2; s.k = (int32_t)(v1 >> 4); s.m2 = (int32_t)(v2 >> 4);
+        if (s.k <= 0 || s.m2 <= 0) return false;
+        has_tail = m == 4; tail = v3;
+    } else {
+        has_tail = m == 2; tail = v1;
+    }
+    if (has_tail) {
+        if ((tail & 15u) != OP_S) return false;
+        s.c = (int32_t)(tail >> 4);
+        if (s.c <= 0) return false;
+    }
+    return s.query_len() == lseq;
+}
+
 // get_pos_on_query (A:389-412) on the shape
 AMP_HD int32_t cig2_pos_on_query(const Cig2 &s, int64_t ref_pos, int64_t ref_start) {
     int64_t q = s.a, cur = ref_start;

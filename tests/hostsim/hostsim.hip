@@ -93,10 +93,14 @@ extern "C" long sim_cig2_fuzz(uint64_t seed, long iters, long *n_punt, long *n_c
         const int kind = rin(0, 2);
         const int32_t m1 = rin(1, 60), k = kind ? rin(1, 6) : 0, m2 = kind ? rin(1, 60) : 0;
         const uint32_t op = (rnd() % 8 == 0) ? OP_EQ : OP_M;
-        uint32_t in[3]; int n = 0;
+        // (a third of the reads arrive with soft clips at one or both ends, as aligners leave them)
+        const int32_t sa = rnd() % 3 == 0 ? rin(1, 30) : 0, sc = rnd() % 3 == 0 ? rin(1, 30) : 0;
+        uint32_t in[5] = {0, 0, 0, 0, 0}; int n = 0;
+        if (sa) in[n++] = ((uint32_t)sa << 4) | OP_S;
         in[n++] = ((uint32_t)m1 << 4) | op;
         if (kind) { in[n++] = ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D); in[n++] = ((uint32_t)m2 << 4) | op; }
-        const int32_t lseq = m1 + (kind == 1 ? k : 0) + m2;
+        if (sc) in[n++] = ((uint32_t)sc << 4) | OP_S;
+        const int32_t lseq = sa + m1 + (kind == 1 ? k : 0) + m2 + sc;
         const int32_t pos = rin(0, 420);
         const uint32_t flag = (rnd() & 1u) | ((rnd() & 1u) << 4);
         const int32_t tlen = (rnd() & 1) ? rin(-600, 600) : 0;
@@ -116,7 +120,11 @@ extern "C" long sim_cig2_fuzz(uint64_t seed, long iters, long *n_punt, long *n_c
         trim_read_serial(P, st, flag, tlen, lseq, qual.data(), true, cur, tmp);
         // closed forms
         Cig2 s;
-        if (!cig2_from_words(n, in[0], n > 1 ? in[1] : 0u, n > 2 ? in[2] : 0u, lseq, s)) { ++bad; continue; }
+        if (!cig2_from_words5(n, in, lseq, s)) { ++bad; continue; }
+        if (!sa && !sc) {       // the three-word form agrees on inputs without clips
+            Cig2 s3;
+            if (!cig2_from_words(n, in[0], n > 1 ? in[1] : 0u, n > 2 ? in[2] : 0u, lseq, s3) || s3.m1 != s.m1 || s3.k != s.k || s3.m2 != s.m2 || s3.kind != s.kind) { ++bad; continue; }
+        }
         TrimState t2{pos, n, 0u, 0};
         const int32_t rs = pos, re1 = pos + s.ref_len() - 1;
         if ((uint32_t)rs >= (uint32_t)G || (uint32_t)re1 >= (uint32_t)G) t2.err = AMP_RS_INDEX_REF;

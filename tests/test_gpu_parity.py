@@ -417,7 +417,7 @@ def test_function_level_seams_replay_the_named_cases():
 @pytest.mark.parametrize("seed,mq,w,off", [(41, 20, 4, 0), (42, 10, 1, 2), (43, 30, 8, 1), (44, 0, 3, 0), (45, 25, 6, 3), (46, 20, 2, 0)])
 def test_short_reads_with_one_indel(runner, seed, mq, w, off):
     """The shapes the fast kernel does in closed form (amp_fast.hpp / Cig2 in amp_read.hpp): reads of up to 152 bases with one
-    match op or two around ONE insertion / deletion, dense primer tables so that the clips of A:450-558 and A:589-686 often
+    match op or two around ONE insertion / deletion, with or without soft clips at the ends, dense primer tables so that the clips of A:450-558 and A:589-686 often
     stop inside or right in front of the indel, low-quality runs inside insertions (several events per insertion), reads
     at reference position 0 (A:735-736), at the end of the reference, with N calls of good quality, and piles further
     apart than the kernel's packed window.  Trim results, count table and insertion events against the oracle."""
@@ -432,11 +432,13 @@ def test_short_reads_with_one_indel(runner, seed, mq, w, off):
         for _ in range(int(rng.integers(20, 140))):                      # a pile of reads per start, jittered
             kind = int(rng.integers(0, 3))
             m1 = int(rng.integers(1, 100)); k = int(rng.integers(1, 9)) if kind else 0; m2 = int(rng.integers(1, 60)) if kind else 0
-            L = m1 + (k if kind == 1 else 0) + m2
+            sa = int(rng.integers(1, 25)) if rng.random() < 0.3 else 0      # soft clips at the ends, as aligners leave them
+            sc = int(rng.integers(1, 25)) if rng.random() < 0.3 else 0
+            L = sa + m1 + (k if kind == 1 else 0) + m2 + sc
             if L > 152:
                 continue
             op = 7 if rng.random() < 0.1 else 0
-            cig = [(op, m1)] + ([(kind, k), (op, m2)] if kind else [])
+            cig = ([(4, sa)] if sa else []) + [(op, m1)] + ([(kind, k), (op, m2)] if kind else []) + ([(4, sc)] if sc else [])
             pos = int(min(max(s0 + rng.integers(-3, 4), 0), G - (m1 + m2 + (k if kind == 2 else 0)) - 1))
             q = rng.choice([37, 25, 11, 2], L, p=[0.7, 0.15, 0.1, 0.05]).astype(np.int64)
             t = int(rng.integers(0, 25))
