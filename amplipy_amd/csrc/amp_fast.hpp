@@ -360,7 +360,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     struct Cg { uint32_t w[5]; };
     struct Geo { uint32_t np, phi, row, Tq; int ntake; bool solo, taken, fastq; };
     struct Tabs { int32_t L, R; };
-    struct Bytes { uint2 raws[F_STAGE / 1024]; };
+    struct Bytes { uint4 raws[F_STAGE / 2048]; };
     struct Shape { Cig2 s; bool ok; int32_t refspan; };
     auto load_hdr = [&](int64_t t0) {
         Hdr h{0, 0, 0u, 0u, 0u, 0u, 0u};
@@ -427,13 +427,13 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         return t;
     };
     // the tile's quality bytes by LDS-DMA (lane l moves bytes [1024 s + 16 l, + 16) of the run to the same offset of
-    // the staging buffer) and its packed bases (8 bytes per lane and load)
+    // the staging buffer) and its packed bases (16 bytes per lane and load)
     auto issue_bytes = [&](const Geo &g, uint32_t m0) {
         Bytes x;
         const uint8_t *qrun = rd.qual + (int64_t)m0 * 8;
         const uint8_t *srun = rd.seq + (int64_t)m0 * 4;
         // lanes past the run re-read its end
-        const uint32_t lastq = g.Tq ? (g.Tq - 1u) & ~15u : 0u, lasts = g.Tq ? ((g.Tq >> 1) - 1u) & ~7u : 0u;
+        const uint32_t lastq = g.Tq ? (g.Tq - 1u) & ~15u : 0u, lasts = g.Tq ? ((g.Tq >> 1) - 1u) & ~15u : 0u;
 #pragma unroll
         for (int sl = 0; sl < F_STAGE / 1024; ++sl) {
             uint32_t off = (uint32_t)(sl * 1024 + lane * 16);
@@ -442,11 +442,11 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                                              (__attribute__((address_space(3))) void *)(stage + sl * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int sl = 0; sl < F_STAGE / 1024; ++sl) {
-            uint32_t off = (uint32_t)(sl * 512 + lane * 8);
+        for (int sl = 0; sl < F_STAGE / 2048; ++sl) {
+            uint32_t off = (uint32_t)(sl * 1024 + lane * 16);
             off = off < lasts ? off : lasts;
             const uint32_t *sp = (const uint32_t *)(srun + off);
-            x.raws[sl] = make_uint2(sp[0], sp[1]);
+            x.raws[sl] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
         }
         return x;
     };
@@ -588,7 +588,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const amp_u32x2 bq0 = *(const lds_u32x2 *)(lq + g_b), bq1 = *(const lds_u32x2 *)(lq + g_b + 8);
         wave_sync();
 #pragma unroll
-        for (int sl = 0; sl < F_STAGE / 1024; ++sl) *(lds_u32x2 *)(stage + sl * 512 + lane * 8) = amp_u32x2{xA.raws[sl].x, xA.raws[sl].y};
+        for (int sl = 0; sl < F_STAGE / 2048; ++sl) *(lds_u32x4 *)(stage + sl * 1024 + lane * 16) = amp_u32x4{xA.raws[sl].x, xA.raws[sl].y, xA.raws[sl].z, xA.raws[sl].w};
         wave_sync();
 #pragma unroll
         for (int k = 0; k < F_NP; ++k) {

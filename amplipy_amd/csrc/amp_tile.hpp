@@ -51,6 +51,8 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef uint32_t amp_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) amp_u32x2 lds_u32x2;
+typedef uint32_t amp_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) amp_u32x4 lds_u32x4;
 
 // entries of the deferred list: read index | kind
 constexpr uint32_t DEFER_STATUS_ONLY = 0x80000000u;   // counted by the tile kernel; only the exact status is missing
