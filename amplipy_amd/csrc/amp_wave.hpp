@@ -1,0 +1,566 @@
+// amp_wave.hpp -- one read per WAVE: the second pass's treatment of reads with tens or hundreds of CIGAR ops
+// (Nanopore-like amplicon reads), written for CDNA4 / gfx950.
+//
+// The serial code of amp_read.hpp walks the ops of a read several times per trim stage; on one lane, with the CIGAR
+// in global memory, that is tens of dependent memory round trips per stage.  Here the CIGAR lives in the wave's own
+// LDS rows and lane = op: every loop of the reference over the ops (A:389-412 get_pos_on_query, A:363-386
+// get_pos_on_ref, the clip loops A:467-510 / A:524-555 / A:597-622 / A:658-683, fix_cigar A:415-423) becomes a
+// prefix sum over the 64 lanes plus a compaction; the sliding quality window (A:566-587, A:630-649) is evaluated
+// at 512 positions at once (lane = 8 consecutive bases), and update_base_counts (A:690-753) runs as lane = 8 bases
+// for the match ops and lane = op for deletions and insertion runs.
+//
+// The path takes reads it can treat exactly with these closed forms: ops M I D N S = X only, no zero-length op,
+// query lengths summing to l_seq, qualities present, window <= 8.  wave_read() returns false for anything else
+// and the caller runs the serial code (so does a counting error: the exact walk then finds the first one in pair order).
+#pragma once
+
+#include "amp_tile.hpp"
+
+namespace amp {
+
+constexpr int WV_MAXOPS = 512;     // words per CIGAR row in LDS (input ops <= WV_MAXOPS - 4)
+constexpr int WV_EVCAP = 128;      // insertion events staged per wave
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts: no LDS traffic)
+__device__ __forceinline__ uint32_t wv_scan(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t wv_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
+__device__ __forceinline__ uint32_t wv_sum(uint32_t x) { return wv_last(wv_scan(x)); }
+
+struct WvNullSink {   // dry run of the exact walk: only the status matters
+    __device__ void add(int32_t, uint32_t) {}
+    __device__ void event(int32_t, int32_t, int32_t) {}
+};
+
+// a CIGAR row in LDS seen by the serial code (fallbacks run on lane 0)
+struct LdsRow {
+    lds_u32 *p;
+    __device__ __forceinline__ uint32_t get(int i) const { return p[i]; }
+    __device__ __forceinline__ void set(int i, uint32_t v) const { p[i] = v; }
+};
+
+// A:389-412 get_pos_on_query: the first reference-consuming op that reaches ref_pos decides.
+__device__ __forceinline__ int32_t wv_pos_on_query(const lds_u32 *c, int n, int32_t ref_pos, int32_t ref_start, int lane) {
+    int32_t qc = 0, rc = ref_start;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < n;
+        const uint32_t v = valid ? c[i] : 0u, op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        const int32_t lq = valid && consumes_query(op) ? len : 0, lr = valid && consumes_ref(op) ? len : 0;
+        const int32_t iq = (int32_t)wv_scan((uint32_t)lq), ir = (int32_t)wv_scan((uint32_t)lr);
+        const int32_t Q = qc + iq - lq, R = rc + ir - lr;
+        const unsigned long long hit = __ballot(valid && consumes_ref(op) && ref_pos <= R + len);
+        if (hit) {
+            const int h = __ffsll((long long)hit) - 1;
+            const int32_t res = consumes_query(op) ? Q + (ref_pos - R) : Q;
+            return __builtin_amdgcn_readlane(res, h);
+        }
+        qc += (int32_t)wv_last((uint32_t)iq); rc += (int32_t)wv_last((uint32_t)ir);
+    }
+    return qc;
+}
+
+// A:363-386 get_pos_on_ref
+__device__ __forceinline__ int32_t wv_pos_on_ref(const lds_u32 *c, int n, int32_t query_pos, int32_t ref_start, int lane) {
+    int32_t qc = 0, rc = ref_start;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < n;
+        const uint32_t v = valid ? c[i] : 0u, op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        const int32_t lq = valid && consumes_query(op) ? len : 0, lr = valid && consumes_ref(op) ? len : 0;
+        const int32_t iq = (int32_t)wv_scan((uint32_t)lq), ir = (int32_t)wv_scan((uint32_t)lr);
+        const int32_t Q = qc + iq - lq, R = rc + ir - lr;
+        const unsigned long long hit = __ballot(valid && consumes_query(op) && query_pos <= Q + len);
+        if (hit) {
+            const int h = __ffsll((long long)hit) - 1;
+            const int32_t res = consumes_ref(op) ? R + (query_pos - Q) : R;
+            return __builtin_amdgcn_readlane(res, h);
+        }
+        qc += (int32_t)wv_last((uint32_t)iq); rc += (int32_t)wv_last((uint32_t)ir);
+    }
+    return rc;
+}
+
+// appends every lane's 0..2 words to dst in lane order
+__device__ __forceinline__ void wv_emit(lds_u32 *dst, int &m, int cnt, uint32_t w0, uint32_t w1) {
+    const uint32_t ic = wv_scan((uint32_t)cnt);
+    const int at = m + (int)ic - cnt;
+    if (cnt >= 1) dst[at] = w0;
+    if (cnt == 2) dst[at + 1] = w1;
+    m += (int)wv_last(ic);
+}
+
+// Primer clip (the per-op rules shared by A:467-510 and A:524-555) of `del` query bases from the front of the walk
+// order (rev: the ops are walked from the back, as the reference walks reversed(cigar)).  With Q = query bases in front of
+// an op, the loop's state at that op is del_before = max(del - Q, 0); the op that sets pos_start is the first one
+// that consumes both and is not used up (del_before < len).  In front of it: query-consuming ops become soft clips (a
+// partly used I / S splits), D / N are dropped and advance the start; from it on everything is copied.
+// Unmerged result -> dst (walk order), returns its length; adv = reference advance (A:514).
+__device__ __forceinline__ int wv_primer_clip(const lds_u32 *src, int n, bool rev, int32_t del, lds_u32 *dst, int lane, int32_t &adv) {
+    int32_t qc = 0, sp = 0;
+    int m = 0;
+    bool resolved = false;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < n;
+        const uint32_t v = valid ? src[rev ? n - 1 - i : i] : 0u, op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        uint32_t w0 = v, w1 = 0u;
+        int cnt = valid ? 1 : 0;
+        int32_t add = 0;
+        if (!resolved) {
+            const int32_t lq = valid && consumes_query(op) ? len : 0;
+            const int32_t iq = (int32_t)wv_scan((uint32_t)lq);
+            const int32_t Q = qc + iq - lq;
+            const int32_t db = del - Q > 0 ? del - Q : 0;
+            const bool both = consumes_query(op) && consumes_ref(op);
+            const unsigned long long pm = __ballot(valid && both && db < len);
+            const int p = pm ? __ffsll((long long)pm) - 1 : 64;
+            if (valid && lane <= p) {
+                if (lane == p) {
+                    if (db > 0) { w0 = ((uint32_t)db << 4) | OP_S; w1 = ((uint32_t)(len - db) << 4) | op; cnt = 2; add = db; }
+                } else if (consumes_query(op)) {
+                    if (db >= len) { w0 = ((uint32_t)len << 4) | OP_S; if (consumes_ref(op)) add = len; }
+                    else if (db > 0) { w0 = ((uint32_t)db << 4) | OP_S; w1 = ((uint32_t)(len - db) << 4) | op; cnt = 2; }
+                    else w0 = ((uint32_t)len << 4) | OP_S;
+                } else {
+                    cnt = 0; add = len;            // D / N (the only ops left on this path): dropped, the start moves on
+                }
+            }
+            resolved = pm != 0ull;
+            qc += (int32_t)wv_last((uint32_t)iq);
+            sp += (int32_t)wv_sum((uint32_t)add);
+        }
+        wv_emit(dst, m, cnt, w0, w1);
+    }
+    adv = sp;
+    return m;
+}
+
+// Quality clip (A:597-622; A:658-683 over the reversed CIGAR) of `del` bases: soft clips pass through without using
+// any of it, M / I / = / X are clipped (the partly used one splits), D / N in front of the cut are dropped; once
+// del is used up everything is copied.
+__device__ __forceinline__ int wv_quality_clip(const lds_u32 *src, int n, bool rev, int32_t del, lds_u32 *dst, int lane) {
+    int32_t qc = 0;
+    int m = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < n;
+        const uint32_t v = valid ? src[rev ? n - 1 - i : i] : 0u, op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        const bool eats = valid && consumes_query(op) && op != OP_S;
+        const int32_t lq = eats ? len : 0;
+        const int32_t iq = (int32_t)wv_scan((uint32_t)lq);
+        const int32_t Q = qc + iq - lq;
+        const int32_t db = del - Q > 0 ? del - Q : 0;
+        uint32_t w0 = v, w1 = 0u;
+        int cnt = valid ? 1 : 0;
+        if (valid && db > 0 && op != OP_S) {
+            if (eats) {
+                w0 = ((uint32_t)(db < len ? db : len) << 4) | OP_S;
+                if (len > db) { w1 = ((uint32_t)(len - db) << 4) | op; cnt = 2; }
+            } else {
+                cnt = 0;
+            }
+        }
+        qc += (int32_t)wv_last((uint32_t)iq);
+        wv_emit(dst, m, cnt, w0, w1);
+    }
+    return m;
+}
+
+// fix_cigar (A:415-423): runs of the same op collapse into one.  u[0..m) is in walk order; the merged CIGAR goes to
+// dst in CIGAR order (rev: back to front).  z is scratch (run-end prefix sums); the front of u is reused for the ops.
+__device__ __forceinline__ int wv_merge(lds_u32 *u, int m, lds_u32 *z, lds_u32 *dst, bool rev, int lane) {
+    uint32_t pc = 0;
+    int kc = 0;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int j = c0 + lane;
+        const bool valid = j < m;
+        const uint32_t v = valid ? u[j] : 0u, op = v & 15u;
+        const uint32_t nxt = j + 1 < m ? u[j + 1] & 15u : 16u;
+        const bool last = valid && op != nxt;
+        const uint32_t ip = wv_scan(valid ? v >> 4 : 0u), il = wv_scan(last ? 1u : 0u);
+        wave_sync();                      // every lane holds its words: the compacted ops may overwrite the front of u
+        if (last) { const int k = kc + (int)il - 1; z[k] = pc + ip; u[k] = op; }
+        pc += wv_last(ip); kc += (int)wv_last(il);
+    }
+    wave_sync();
+    for (int k0 = 0; k0 < kc; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < kc) dst[rev ? kc - 1 - k : k] = ((z[k] - (k ? z[k - 1] : 0u)) << 4) | u[k];
+    }
+    wave_sync();
+    return kc;
+}
+
+// 8 bytes starting at byte B (0..8) of the 16-byte group (a, b)
+template <int B>
+__device__ __forceinline__ uint2 wv_bytes8(const uint2 a, const uint2 b) {
+    const uint32_t w[5] = {a.x, a.y, b.x, b.y, 0u};
+    constexpr int d = B >> 2, sh = (B & 3) * 8;
+    if (sh == 0) return make_uint2(w[d], w[d + 1]);
+    return make_uint2(__builtin_amdgcn_alignbit(w[d + 1], w[d], sh), __builtin_amdgcn_alignbit(w[d + 2], w[d + 1], sh));
+}
+__device__ __forceinline__ uint32_t wv_sum8(const uint2 x) { return __builtin_amdgcn_sad_u8(x.y, 0u, __builtin_amdgcn_sad_u8(x.x, 0u, 0u)); }
+
+// The sliding-window scan of A:566-587 (reverse strand: returns i = number of leading bases to clip) and A:630-649
+// (forward strand: i = number of leading bases kept) over the qualities q[lo .. lo+qlen) of the read: at step i the
+// window holds w = min(width, bases left) bases and the scan stops at the first i whose window sums to less than
+// min_quality * w.  Every lane tests the 8 steps that belong to its 8 bases; the first failing one in scan order wins.
+// `q` is the read's first quality byte (8-byte aligned, readable up to 16 bytes past the read).
+__device__ __forceinline__ int32_t wv_quality_scan(const uint8_t *q, int32_t lseq, int32_t lo, int32_t qlen, int32_t width,
+                                                   int32_t min_quality, bool reverse, int lane) {
+    const int32_t W = width < qlen ? width : qlen;
+    if (qlen <= 0) return 0;
+    const int32_t hi = lo + qlen;
+    const int b_first = lo >> 9, b_last = (hi - 1) >> 9;
+    for (int blk = reverse ? b_last : b_first; reverse ? blk >= b_first : blk <= b_last; blk += reverse ? -1 : 1) {
+        const int32_t p8 = blk * 512 + lane * 8;          // this lane's first base
+        // forward: the window of a step starts on its base and needs the 7 bytes after the lane's own 8;
+        // reverse: it ends on its base and needs the 7 bytes before
+        const int32_t o0 = reverse ? p8 - 8 : p8;
+        const uint2 a = o0 >= 0 && o0 < lseq ? *(const uint2 *)(q + o0) : make_uint2(0u, 0u);
+        const uint2 b = o0 + 8 >= 0 && o0 + 8 < lseq ? *(const uint2 *)(q + o0 + 8) : make_uint2(0u, 0u);
+        uint32_t fail = 0u;
+#define WV_STEP(B)                                                                                                        \
+        {                                                                                                                     \
+            const int32_t p = p8 + B;                                                                                         \
+            if (reverse) {                                                                                                    \
+                const int32_t i = p + 1 - lo;                  /* the step whose window ends on base p */                     \
+                if (i >= 1 && i <= qlen) {                                                                                    \
+                    const int32_t w = W < i ? W : i;                                                                          \
+                    uint2 x = wv_bytes8<B + 1>(a, b);          /* the 8 bytes that end on p */                                \
+                    const int drop = (8 - w) * 8;              /* keep the top w of them */                                   \
+                    if (drop >= 32) { x.x = 0u; x.y = (x.y >> (drop - 32)) << (drop - 32); }                                  \
+                    else if (drop) x.x = (x.x >> drop) << drop;                                                               \
+                    if ((int32_t)wv_sum8(x) < min_quality * w) fail |= 1u << B;                                               \
+                }                                                                                                             \
+            } else {                                                                                                          \
+                const int32_t i = p - lo;                                                                                     \
+                if (i >= 0 && i < qlen) {                                                                                     \
+                    const int32_t w = W < qlen - i ? W : qlen - i;                                                            \
+                    uint2 x = wv_bytes8<B>(a, b);              /* the 8 bytes that start on p */                              \
+                    const int drop = (8 - w) * 8;              /* keep the low w of them */                                   \
+                    if (drop >= 32) { x.y = 0u; x.x = (x.x << (drop - 32)) >> (drop - 32); }                                  \
+                    else if (drop) x.y = (x.y << drop) >> drop;                                                               \
+                    if ((int32_t)wv_sum8(x) < min_quality * w) fail |= 1u << B;                                               \
+                }                                                                                                             \
+            }                                                                                                                 \
+        }
+        WV_STEP(0) WV_STEP(1) WV_STEP(2) WV_STEP(3) WV_STEP(4) WV_STEP(5) WV_STEP(6) WV_STEP(7)
+#undef WV_STEP
+        const unsigned long long any = __ballot(fail != 0u);
+        if (any) {
+            if (reverse) {
+                const int l = 63 - __clzll((long long)any);
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fail, l);
+                return blk * 512 + l * 8 + (31 - __clz((int)f)) + 1 - lo;
+            }
+            const int l = __ffsll((long long)any) - 1;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fail, l);
+            return blk * 512 + l * 8 + (__ffs((int)f) - 1) - lo;
+        }
+    }
+    return reverse ? 0 : qlen;
+}
+
+// Counters and insertion events of the wave path: counts through the block's LDS window like WinSink; events staged in the
+// wave's own area and moved to the list with one reservation per flush (wv_flush_events).
+struct WaveSink {
+    lds_u32 *win;
+    int32_t base;
+    uint32_t win_n;       // positions per plane of the window
+    uint32_t ev_plane;    // plane index of the insertion-event tally
+    uint32_t *counts;
+    const EventBuf &eb;
+    uint32_t read;
+    lds_u32 *ev, *nev;
+    __device__ void add(int32_t r, uint32_t col) {
+        const uint32_t d = (uint32_t)(r - base);
+        if (d < win_n) lds_add(win + col * win_n + d, 1u);
+        else atomicAdd(&counts[(size_t)r * AMP_NSYM + col], 1u);
+    }
+    __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+        const uint32_t k = __hip_atomic_fetch_add(nev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k < (uint32_t)WV_EVCAP) {
+            ev[k * 4] = (uint32_t)pos; ev[k * 4 + 1] = read; ev[k * 4 + 2] = (uint32_t)lo; ev[k * 4 + 3] = (uint32_t)hi;
+            const uint32_t d = (uint32_t)(pos - base);
+            if (d < win_n) lds_add(win + ev_plane * win_n + d, 1u);
+            else atomicAdd(&eb.ins_at[pos], 1u);
+        } else {
+            eb.record(pos, read, lo, hi);
+        }
+    }
+};
+
+// the wave's staged events -> the block's shard of the list (one reservation)
+__device__ __forceinline__ void wv_flush_events(const EventBuf &eb, lds_u32 *ev, lds_u32 *nev, int lane) {
+    wave_sync();
+    const uint32_t staged = *nev;
+    const uint32_t n = staged < (uint32_t)WV_EVCAP ? staged : (uint32_t)WV_EVCAP;
+    if (n == 0u) return;
+    const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
+    unsigned long long b0 = 0ull;
+    if (lane == 0) b0 = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)n);
+    b0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64u)
+        if ((long long)(b0 + k) < eb.cap)
+            eb.ev[(size_t)shard * (size_t)eb.cap + b0 + k] = amp_ins_event{(int32_t)ev[k * 4], ev[k * 4 + 1], (int32_t)ev[k * 4 + 2], (int32_t)ev[k * 4 + 3]};
+    wave_sync();
+    if (lane == 0) *nev = 0u;
+    wave_sync();
+}
+
+// One read on one wave: trims (A:426-687), outputs, counts (A:690-753).  x, y, z: the wave's three LDS rows of WV_MAXOPS
+// words.  Returns false -- with nothing written anywhere -- when the read is not one for this path.
+template <class Sink>
+__device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink, const EventBuf &eb,
+                          lds_u32 *x, lds_u32 *y, lds_u32 *z, int lane) {
+    const uint32_t c0 = rd.cig_off32[i];
+    int n = (int)(rd.cig_off32[i + 1] - c0);
+    const int32_t lseq = (int32_t)rd.lseq[i];
+    int32_t pos = rd.pos[i];
+    const uint32_t flag = rd.flag[i];
+    const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
+    const uint8_t *qual = rd.qual + boff;
+    if (n < 1 || n > WV_MAXOPS - 4 || lseq <= 0 || pos < 0 || P.window < 1 || P.window > 8) return false;
+    // ---- the ops into row x; is this a read for the closed forms?
+    uint32_t qsum = 0u, rsum = 0u;
+    bool dirty = false;
+    for (int c = 0; c < n; c += 64) {
+        const int k = c + lane;
+        const uint32_t v = k < n ? rd.cig[c0 + k] : (1u << 4), op = v & 15u;
+        if (k < n) x[k] = v;
+        dirty |= !((0x19Fu >> op) & 1u) || (v >> 4) == 0u;         // M I D N S = X, no empty op
+        qsum += consumes_query(op) && k < n ? v >> 4 : 0u;
+        rsum += consumes_ref(op) && k < n ? v >> 4 : 0u;
+    }
+    qsum = wv_sum(qsum); rsum = wv_sum(rsum);
+    if (__ballot(dirty) || qsum != (uint32_t)lseq || qual[0] == 0xFFu) return false;
+    wave_sync();
+    uint32_t tflags = 0u;
+    if (P.do_trim) {
+        const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
+        const int32_t re1 = pos + (int32_t)(rsum ? rsum : 1u) - 1;
+        if ((uint32_t)pos >= (uint32_t)P.ref_len || (uint32_t)re1 >= (uint32_t)P.ref_len) return false;     // A:450-451 raise
+        const int32_t left_max_end = P.max_end[pos], right_min_start = P.min_start[re1];
+        const int32_t tl = rd.tlen[i], at = tl < 0 ? -tl : tl;
+        const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;                            // A:452
+        const bool do_left = !(is_paired && isize_flag && is_reverse) && left_max_end >= 0;                  // A:460
+        const bool do_right = !(is_paired && isize_flag && !is_reverse) && right_min_start >= 0;             // A:517
+        // the clips below change x: a case left to the serial code has to be seen before the first of them
+        int32_t del_l = 0;
+        if (do_left) {
+            del_l = wv_pos_on_query(x, n, left_max_end + 1, pos, lane);                                      // A:463
+            if (del_l < 0) return false;
+        }
+        if (do_left) {
+            tflags |= AMP_TRIM_PRIMER_START;
+            int32_t adv;
+            const int m = wv_primer_clip(x, n, false, del_l, y, lane, adv);
+            n = wv_merge(y, m, z, x, false, lane);
+            pos += adv;                                                                                      // A:514
+        }
+        if (do_right) {
+            tflags |= AMP_TRIM_PRIMER_END;
+            const int32_t del = lseq - wv_pos_on_query(x, n, right_min_start, pos, lane);                    // A:520
+            int32_t adv;
+            const int m = wv_primer_clip(x, n, true, del, y, lane, adv);
+            n = wv_merge(y, m, z, x, true, lane);
+        }
+        // A:561 query_alignment_qualities of the clipped read: leading soft clips, trailing soft clips (element 0 is never
+        // looked at from the back)
+        int32_t qs = 0, trail = 0;
+        {
+            int first_other = n, last_other = -1;
+            for (int c = 0; c < n; c += 64) {
+                const int k = c + lane;
+                const unsigned long long o = __ballot(k < n && (x[k] & 15u) != OP_S);
+                if (o) { if (first_other == n) first_other = c + __ffsll((long long)o) - 1; last_other = c + 63 - __clzll((long long)o); }
+            }
+            uint32_t a = 0u, b = 0u;
+            for (int c = 0; c < n; c += 64) {
+                const int k = c + lane;
+                const uint32_t len = k < n ? x[k] >> 4 : 0u;
+                a += k < first_other ? len : 0u;
+                b += k > last_other && k >= 1 ? len : 0u;
+            }
+            qs = (int32_t)wv_sum(a); trail = (int32_t)wv_sum(b);
+        }
+        int32_t lo, hi;
+        py_slice(qs, lseq - trail, lseq, lo, hi);
+        const int32_t qlen = hi - lo;
+        const int32_t isc = wv_quality_scan(qual, lseq, lo, qlen, P.window, P.min_quality, is_reverse, lane);
+        if (is_reverse) {
+            const int32_t del = isc;
+            const int32_t sp = wv_pos_on_ref(x, n, del + qs - 1, pos, lane);                                 // A:591
+            if (sp > pos) {                                                                                  // A:594
+                tflags |= AMP_TRIM_QUALITY;
+                const int m = wv_quality_clip(x, n, false, del, y, lane);
+                n = wv_merge(y, m, z, x, false, lane);                      // reference_start is NOT advanced
+            }
+        } else {
+            const int32_t del = qlen - isc;
+            if (del != 0) {                                                                                  // A:656
+                tflags |= AMP_TRIM_QUALITY;
+                const int m = wv_quality_clip(x, n, true, del, y, lane);
+                n = wv_merge(y, m, z, x, true, lane);
+            }
+        }
+    }
+    // ---- the final CIGAR: query / reference start of every op (rows y, z), shape
+    int32_t qtot = 0, rtot = 0;
+    int first_body = -1, last_body = -1, n_body = 0;
+    bool twin_ins = false;
+    {
+        uint32_t *home = out.new_cig + (size_t)c0 + 3 * (size_t)i;
+        for (int c = 0; c < n; c += 64) {
+            const int k = c + lane;
+            const bool valid = k < n;
+            const uint32_t v = valid ? x[k] : 0u, op = v & 15u;
+            const int32_t len = (int32_t)(v >> 4);
+            if (valid) home[k] = v;
+            const int32_t lq = valid && consumes_query(op) ? len : 0, lr = valid && consumes_ref(op) ? len : 0;
+            const int32_t iq = (int32_t)wv_scan((uint32_t)lq), ir = (int32_t)wv_scan((uint32_t)lr);
+            if (valid) { y[k] = (uint32_t)(qtot + iq - lq); z[k] = (uint32_t)(pos + rtot + ir - lr); }
+            const unsigned long long body = __ballot(valid && op != OP_S);
+            if (body) {
+                if (first_body < 0) first_body = c + __ffsll((long long)body) - 1;
+                last_body = c + 63 - __clzll((long long)body);
+                n_body += __popcll(body);
+            }
+            twin_ins |= __ballot(valid && op == OP_I && k + 1 < n && (x[k + 1] & 15u) == OP_I) != 0ull;
+            qtot += (int32_t)wv_last((uint32_t)iq); rtot += (int32_t)wv_last((uint32_t)ir);
+        }
+    }
+    wave_sync();
+    const int32_t ref_len_final = rtot ? rtot : 1;
+    if (lane == 0) {
+        if (out.new_pos) out.new_pos[i] = pos;
+        if (out.new_ncig) out.new_ncig[i] = (uint32_t)n;
+        if (out.ref_len) out.ref_len[i] = ref_len_final;
+        if (out.trim_flags) out.trim_flags[i] = (uint8_t)tflags;
+    }
+    int err = 0;
+    if (P.do_count) {
+        const uint32_t G = (uint32_t)P.ref_len;
+        const int32_t mq = P.min_quality;
+        const bool regular = (n_body == 0 || last_body - first_body + 1 == n_body) && !twin_ins;
+        if (!regular) {
+            // soft clips inside the alignment, two insertions in a row: the exact walk on one lane, CIGAR in LDS
+            if (lane == 0) err = count_read_walk(P, LdsRow{x}, n, pos, lseq, ReadBytesCached{rd.seq, boff, qual}, true, sink);
+        } else if (n_body) {
+            const int32_t ref_end = pos + ref_len_final;
+            bool bad = false;
+            // match bases: lane = 8 consecutive query bases
+            for (int32_t q0 = 0; q0 < lseq; q0 += 512) {
+                const int32_t q8 = q0 + lane * 8;
+                if (q8 < lseq) {
+                    const uint2 qq = *(const uint2 *)(qual + q8);
+                    const uint32_t sw = *(const uint32_t *)(rd.seq + ((boff + q8) >> 1));
+                    // the op that holds base q8: the last one that starts at or before it
+                    int lo_k = 0, hi_k = n - 1;
+                    while (lo_k < hi_k) { const int mid = (lo_k + hi_k + 1) >> 1; if ((int32_t)y[mid] <= q8) lo_k = mid; else hi_k = mid - 1; }
+                    int k = lo_k;
+                    uint32_t v = x[k];
+                    int32_t left = (int32_t)y[k] + (int32_t)(v >> 4) - q8;          // bases of this op from q8 on
+                    int32_t r = (int32_t)z[k] + (q8 - (int32_t)y[k]);
+                    const int nb = lseq - q8 < 8 ? lseq - q8 : 8;
+                    for (int b = 0; b < nb; ++b) {
+                        while (left == 0) {                                           // next query-consuming op
+                            v = x[++k];
+                            if (consumes_query(v & 15u)) { left = (int32_t)(v >> 4); r = (int32_t)z[k]; }
+                        }
+                        if (is_match_op(v & 15u)) {
+                            const uint32_t qb = ((b & 4 ? qq.y : qq.x) >> ((b & 3) * 8)) & 0xFFu;
+                            if ((int32_t)qb >= mq) {                                                         // A:718
+                                const uint32_t byte = (sw >> ((b >> 1) * 8)) & 0xFFu;
+                                const uint32_t col = col_of_code((b & 1) ? (byte & 15u) : (byte >> 4));
+                                if (col > 4u || (uint32_t)r >= G) bad = true;
+                                else sink.add(r, col);                                                       // A:751-753
+                            }
+                            ++r;
+                        }
+                        --left;
+                    }
+                }
+            }
+            // deletions / reference skips and insertion runs: lane = op
+            const QualAt qf{qual};
+            for (int c = 0; c < n; c += 64) {
+                const int k = c + lane;
+                if (k >= n) continue;
+                const uint32_t v = x[k], op = v & 15u;
+                const int32_t len = (int32_t)(v >> 4);
+                if (op == OP_D || op == OP_N) {                                                              // A:714-715
+                    const int32_t r0 = (int32_t)z[k];
+                    for (int32_t j = 0; j < len; ++j) {
+                        if ((uint32_t)(r0 + j) >= G) { bad = true; break; }
+                        sink.add(r0 + j, 5u);
+                    }
+                } else if (op == OP_I) {                                                                     // A:730-748
+                    // one event per maximal run of good bases.  A run that ends inside the op was stopped by a low base,
+                    // which the reference swallows: counted at reference_end - 1.  A run that reaches the op's end looks
+                    // at the pair behind it: a match base (anchor; handed back), a deleted base (q is None: the
+                    // slice runs to the read's end), the first base of the end clip (stops the scan: reference_end
+                    // - 1 again), or nothing (get_aligned_pairs exhausted: IndexError).
+                    const int32_t qa = (int32_t)y[k], r2 = (int32_t)z[k];
+                    const uint32_t nop = k + 1 < n ? x[k + 1] & 15u : 16u;
+                    int32_t j = 0;
+                    while (j < len) {
+                        if ((int32_t)qf(qa + j) < mq) { ++j; continue; }                                     // A:718
+                        const int32_t js = j;
+                        while (j < len && (int32_t)qf(qa + j) >= mq) ++j;
+                        int32_t slo, shi, ins_pos;
+                        if (j < len) {
+                            py_slice(qa + js - 1, qa + j, lseq, slo, shi);                                   // A:738
+                            ins_pos = ref_end; ++j;                                                          // A:739-740
+                        } else if (is_match_op(nop)) {
+                            if (r2 == 0) py_slice(qa + js, qa + len + 1, lseq, slo, shi);                    // A:735-736
+                            else py_slice(qa + js - 1, qa + len, lseq, slo, shi);
+                            ins_pos = r2;                                                                    // A:742
+                        } else if (nop == OP_D || nop == OP_N) {
+                            if (r2 == 0) { bad = true; break; }                                              // None + 1: TypeError
+                            py_slice(qa + js - 1, lseq, lseq, slo, shi);                                     // seq[a:None]
+                            ins_pos = r2;
+                        } else if (nop == OP_S) {
+                            py_slice(qa + js - 1, qa + len, lseq, slo, shi);
+                            ins_pos = ref_end;
+                        } else {
+                            bad = true; break;                                                               // A:734 IndexError
+                        }
+                        ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                                         // A:744
+                        if ((uint32_t)ins_pos >= G) { bad = true; break; }
+                        sink.event(ins_pos, slo, shi);
+                    }
+                }
+            }
+            if (__ballot(bad)) {
+                // some pair cannot be counted: the exact walk names the first error in pair order
+                if (lane == 0) {
+                    WvNullSink ns;
+                    err = count_read_walk(P, LdsRow{x}, n, pos, lseq, ReadBytesCached{rd.seq, boff, qual}, true, ns);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (out.status) out.status[i] = (uint8_t)err;
+        if (err) atomicAdd(&eb.ctr[2], 1ull);
+    }
+    wave_sync();
+    return true;
+}
+
+}  // namespace amp

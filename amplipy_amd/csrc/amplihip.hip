@@ -20,6 +20,7 @@
 #include "amp_read.hpp"
 #include "amp_tile.hpp"
 #include "amp_fast.hpp"
+#include "amp_wave.hpp"
 
 using namespace amp;
 
@@ -324,7 +325,8 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 //     the skip-ahead walk on this lane; the match bases are left to the block's waves (count_match_coop)
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
-constexpr int D_MAXOPS = 20;
+constexpr int D_MAXOPS = 19;      // (with the rest of HeavyLds this lets two blocks share a CU's 160 KB)
+static_assert(4 * 3 * WV_MAXOPS <= 2 * D_MAXOPS * 256 && 4 * WV_EVCAP <= 512, "the wave path's rows and event stages alias the columns / the block's stage");
 template <class CB, class Sink>
 __device__ bool process_read_full(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
                                   const EventBuf &eb, bool status_only, CB &cur, CB &tmp, uint32_t c0, int n,
@@ -466,6 +468,8 @@ struct HeavyLds {
     uint32_t coop[3 * 256];
     uint32_t ev[4 * D_EVCAP];
     uint32_t ucnt[D_UNIT + 1];
+    uint32_t lng[256];              // reads of this round for the wave path (amp_wave.hpp)
+    uint32_t nlong, nslow, wnev[4];
     uint32_t ncoop, nev;
     unsigned long long evbase, mask;
 };
@@ -512,6 +516,7 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
         }
         s_ucnt[D_UNIT] = acc;
         s_ncoop = 0; s_nev = 0;
+        L.nlong = 0; L.nslow = 0; L.wnev[0] = L.wnev[1] = L.wnev[2] = L.wnev[3] = 0;
     }
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
     // sorted input: no read of this pass starts left of the first read of its first tile range
@@ -552,6 +557,9 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
                         s_coop[slot * 3 + 1] = (uint32_t)nf | (threadIdx.x << 22) | (in_b << 30);
                         s_coop[slot * 3 + 2] = (uint32_t)pf;
                     }
+                } else if (!status_only && n <= WV_MAXOPS - 4) {
+                    // tens to hundreds of ops: a wave per read, below
+                    L.lng[atomicAdd(&L.nlong, 1u)] = (uint32_t)i;
                 } else {
                     // longer CIGARs ping-pong in global memory; counts go through the block's window and the
                     // events into a slice of the list reserved once for the read: its bound is the number of
@@ -605,6 +613,36 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
         }
         done += ncoop;
         flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
+        if (L.nlong) {
+            // wave = read (amp_wave.hpp): three CIGAR rows per wave in the columns' space, events staged per wave
+            const uint32_t nlong = L.nlong;
+            const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+            lds_u32 *const row = (lds_u32 *)s_cig + wave * (3 * WV_MAXOPS);
+            lds_u32 *const wev = (lds_u32 *)s_ev + wave * (WV_EVCAP * 4), *const wn = (lds_u32 *)&L.wnev[wave];
+            for (uint32_t c = (uint32_t)wave; c < nlong; c += 4u) {
+                const int64_t i = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.lng[c]);
+                WaveSink ws{(lds_u32 *)s_win, base, D_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn};
+                if (!wave_read(P, rd, i, out, ws, eb, row, row + WV_MAXOPS, row + 2 * WV_MAXOPS, lane)) {
+                    if (lane == 0) s_coop[atomicAdd(&L.nslow, 1u)] = (uint32_t)i;      // not a read for the closed forms
+                }
+                if (*wn > (uint32_t)WV_EVCAP / 2u) wv_flush_events(eb, wev, wn, lane);
+            }
+            wv_flush_events(eb, wev, wn, lane);
+            __syncthreads();
+            const uint32_t nslow = L.nslow;
+            for (uint32_t k = threadIdx.x; k < nslow; k += blockDim.x) {
+                // the exact serial code, CIGAR ping-pong between the output slot and the scratch slot
+                const int64_t i = (int64_t)s_coop[k];
+                const uint32_t c0 = rd.cig_off32[i];
+                const size_t slot = (size_t)c0 + 3 * (size_t)i;
+                WinSink sink{(lds_u32 *)s_win, base, counts, eb, (uint32_t)(read_base + (uint64_t)i), (lds_u32 *)s_ev, (lds_u32 *)&s_nev};
+                process_read_body(P, rd, i, out, sink, eb, false, CigBuf<1>{out.new_cig + slot}, CigBuf<1>{scratch + slot},
+                                  out.new_cig + slot, c0, (int)(rd.cig_off32[i + 1] - c0));
+            }
+            flush_staged_events(eb, s_ev, &s_nev, &s_evbase);
+            if (threadIdx.x == 0) { L.nlong = 0; L.nslow = 0; }
+            __syncthreads();
+        }
     }
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) {
         const uint32_t v = s_win[k];

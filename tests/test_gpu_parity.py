@@ -519,6 +519,59 @@ def test_randomised_parameters_and_read_shapes(runner, seed):
     assert_same(oracle.process(good, g.size, mn, mx, mpl, mq, w), runner.process(good, g.size, mn, mx, mpl, mq, w), good)
 
 
+def _wild_long_segments(rng, n, ref_len):
+    """CIGARs of 18-160 ops drawn op by op: mostly regular bodies, but also clips inside the alignment, hard clips, pads,
+    runs of the same op, insertions at either end or in front of a deletion / the end clip, reads that start on position 0."""
+    from amplipy_amd.segment import Segment
+    segs = []
+    for _ in range(n):
+        n_ops = int(rng.integers(18, 161))
+        wild = rng.random() < 0.25
+        ops, q = [], 0
+        if rng.random() < 0.15 and wild: ops.append((5, int(rng.integers(1, 9))))
+        if rng.random() < 0.5:
+            k = int(rng.integers(1, 25)); ops.append((4, k)); q += k
+        prev = -1
+        while len(ops) < n_ops:
+            if wild:
+                op = int(rng.choice([0, 0, 1, 2, 3, 4, 6, 7, 8, 1, 2]))
+            else:
+                op = int(rng.choice([0, 7, 8])) if prev not in (0, 7, 8) and rng.random() < 0.85 else int(rng.choice([1, 1, 2, 2, 3]))
+                if op == prev: continue
+            k = int(rng.integers(1, 12)) if op not in (0, 7, 8) else int(rng.integers(1, 40))
+            ops.append((op, k)); prev = op
+            if op in (0, 1, 4, 7, 8): q += k
+        if rng.random() < 0.5:
+            k = int(rng.integers(1, 25)); ops.append((4, k)); q += k
+        if rng.random() < 0.1 and wild: ops.append((5, 3))
+        span = sum(k for o, k in ops if o in (0, 2, 3, 7, 8))
+        pos = 0 if rng.random() < 0.03 else int(rng.integers(0, max(1, ref_len - span - 1)))
+        seq = "".join(rng.choice(list("ACGTN"), q, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        qual = rng.choice([37, 25, 11, 2], q, p=[0.93, 0.05, 0.015, 0.005] if rng.random() < 0.6 else [0.6, 0.2, 0.12, 0.08]).astype(np.uint8)
+        segs.append(Segment(flag=int(rng.choice([0, 16, 99, 147])), reference_start=pos, cigar=ops,
+                            template_length=int(rng.integers(-700, 700)), query_sequence=seq, query_qualities=qual.tolist()))
+    return segs
+
+
+@pytest.mark.parametrize("seed,mq,w", [(1, 20, 4), (2, 13, 1), (3, 30, 8), (4, 20, 9), (5, 2, 3), (6, 25, 5)])
+def test_many_op_reads_of_every_shape(runner, seed, mq, w):
+    """The wave-per-read path (amp_wave.hpp) and the cases it hands to the serial code: statuses of all reads, then trims,
+    counts and events of the reads the reference accepts."""
+    G = 40_000
+    rng = np.random.default_rng(seed)
+    primers = sorted((int(s), int(s) + int(rng.integers(18, 31))) for s in rng.integers(0, G - 40, 160))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, int(rng.integers(0, 4)))
+    segs = _wild_long_segments(rng, 1500, G)
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, mq, w)
+    assert_same(a, runner.process(b, G, mn, mx, mpl, mq, w), b, check_counts=False)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    assert len(ok) > 0.5 * len(segs)
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    assert_same(oracle.process(good, G, mn, mx, mpl, mq, w), runner.process(good, G, mn, mx, mpl, mq, w), good)
+
+
 def test_single_rank_rccl_paths(tmp_path, scheme, monkeypatch):
     """The N > 1 code has to have run before an 8-GPU node shows up: (a) amp_reduce with no communicator is a no-op,
     (b) one-rank RCCL all-reduce of the bound device table through torch.distributed (backend nccl) leaves the
