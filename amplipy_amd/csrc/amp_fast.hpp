@@ -897,8 +897,9 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 // segment of fast-kernel block b behind the totals of the blocks before it (the per-block counts are a KB in L2).
 __global__ void __launch_bounds__(256)
 k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt, int reads_per_block, int64_t n_reads,
-           uint32_t *__restrict__ dense, GenGeo *geo, uint32_t gen_grid, unsigned long long *ctr) {
-    __shared__ uint32_t s_part[4];
+           uint32_t *__restrict__ dense, GenGeo *geo, uint32_t gen_grid, unsigned long long *ctr,
+           const uint32_t *__restrict__ cig_off32, uint32_t *__restrict__ llist, uint32_t *__restrict__ lpos, int long_max_ops) {
+    __shared__ uint32_t s_part[4], s_lw[4], s_lbase;
     const int tid = threadIdx.x;
     uint32_t acc = 0;
     for (int b = tid; b < (int)blockIdx.x; b += 256) acc += gcnt[b];
@@ -910,6 +911,44 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
     const int64_t sbeg = (int64_t)blockIdx.x * reads_per_block;
     const uint32_t *src = glist + (sbeg < n_reads ? sbeg : 0);
     for (uint32_t k = tid; k < cnt; k += 256) dense[off + k] = src[k];
+    if (long_max_ops) {
+        // the reads with more ops than the tile kernel's columns hold (it would only pass them on) and no more than k_long's rows:
+        // flagged in the dense list and listed, in order, for k_long (one reservation per block)
+        const auto is_long = [&](uint32_t k) -> bool {
+            if (k >= cnt) return false;
+            const uint32_t e = src[k];
+            if (e & GL_STATUS_ONLY) return false;
+            const uint32_t i = e & GL_INDEX_MASK, nops = cig_off32[i + 1] - cig_off32[i];
+            return (int)nops + 3 > T_MAXOPS && (int)nops <= long_max_ops;
+        };
+        uint32_t mine = 0;
+        for (uint32_t k = tid; k < cnt; k += 256) mine += is_long(k) ? 1u : 0u;
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+        __syncthreads();
+        if ((tid & 63) == 0) s_lw[tid >> 6] = mine;
+        __syncthreads();
+        const uint32_t total = s_lw[0] + s_lw[1] + s_lw[2] + s_lw[3];
+        if (total) {                                   // (uniform over the block)
+            if (tid == 0) s_lbase = (uint32_t)atomicAdd(&ctr[26], (unsigned long long)total);
+            uint32_t run = 0;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 256) {
+                const uint32_t k = k0 + tid;
+                const bool lg = is_long(k);
+                const unsigned long long m = __ballot(lg);
+                __syncthreads();
+                if ((tid & 63) == 0) s_lw[tid >> 6] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t before = run;
+                for (int w = 0; w < (tid >> 6); ++w) before += s_lw[w];
+                if (lg) {
+                    const uint32_t at = s_lbase + before + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+                    llist[at] = src[k] & GL_INDEX_MASK; lpos[at] = off + k;
+                    dense[off + k] = src[k] | GL_LONG;
+                }
+                run += s_lw[0] + s_lw[1] + s_lw[2] + s_lw[3];
+            }
+        }
+    }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const uint32_t n_list = off + cnt;
         const uint32_t tiles = (n_list + TILE - 1) / TILE;

@@ -61,6 +61,7 @@ constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 
 // The general pass of variant 4 (amp_fast.hpp) runs this kernel over a LIST of reads: entries are read index | kind
 constexpr uint32_t GL_STATUS_ONLY = 0x80000000u;   // counted by the fast kernel; a base could not be counted: exact status wanted
+constexpr uint32_t GL_LONG = 0x40000000u;          // tens of CIGAR ops: taken by k_long (amp_wave.hpp), not a row of this pass
 constexpr uint32_t GL_INDEX_MASK = 0x3FFFFFFFu;
 struct GenGeo {            // geometry of the general pass, decided on the device by k_gcompact
     uint32_t n_list;       // entries of the dense list
@@ -625,9 +626,9 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 #define AMP_STAMP(k) do { if (stamps) { unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } } while (0)
         // =================================== P1: lane = read ===================================
         const int64_t li = tile * TILE + lane;           // row of the batch, or of the list
-        const bool valid = li < n;
+        bool valid = li < n;
         uint32_t lent = 0;
-        if (LIST && valid) lent = rlist[li];
+        if (LIST && valid) { lent = rlist[li]; if (lent & GL_LONG) valid = false; }
         const int64_t i = LIST ? (int64_t)(lent & GL_INDEX_MASK) : li;
         const bool status_wanted = LIST && (lent & GL_STATUS_ONLY);      // the fast kernel counted it: exact status only
         int32_t lseq = 0, pos = 0, tlen = 0;

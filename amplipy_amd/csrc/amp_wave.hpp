@@ -204,6 +204,9 @@ __device__ __forceinline__ int wv_merge(lds_u32 *u, int m, lds_u32 *z, lds_u32 *
     return kc;
 }
 
+constexpr int WV_QSTASH = 520;     // quality bytes of a read kept in the wave's LDS stash (512 + the 8 a forward window may reach into)
+__device__ __forceinline__ uint2 wv_lds8(const lds_u8 *p) { const amp_u32x2 v = *(const lds_u32x2 *)p; return make_uint2(v.x, v.y); }
+
 // 8 bytes starting at byte B (0..8) of the 16-byte group (a, b)
 template <int B>
 __device__ __forceinline__ uint2 wv_bytes8(const uint2 a, const uint2 b) {
@@ -219,7 +222,8 @@ __device__ __forceinline__ uint32_t wv_sum8(const uint2 x) { return __builtin_am
 // window holds w = min(width, bases left) bases and the scan stops at the first i whose window sums to less than
 // min_quality * w.  Every lane tests the 8 steps that belong to its 8 bases; the first failing one in scan order wins.
 // `q` is the read's first quality byte (8-byte aligned, readable up to 16 bytes past the read).
-__device__ __forceinline__ int32_t wv_quality_scan(const uint8_t *q, int32_t lseq, int32_t lo, int32_t qlen, int32_t width,
+// The first WV_QSTASH bytes are also in the wave's LDS stash `wq` (filled when the read was loaded).
+__device__ __forceinline__ int32_t wv_quality_scan(const uint8_t *q, const lds_u8 *wq, int32_t lseq, int32_t lo, int32_t qlen, int32_t width,
                                                    int32_t min_quality, bool reverse, int lane) {
     const int32_t W = width < qlen ? width : qlen;
     if (qlen <= 0) return 0;
@@ -230,8 +234,9 @@ __device__ __forceinline__ int32_t wv_quality_scan(const uint8_t *q, int32_t lse
         // forward: the window of a step starts on its base and needs the 7 bytes after the lane's own 8;
         // reverse: it ends on its base and needs the 7 bytes before
         const int32_t o0 = reverse ? p8 - 8 : p8;
-        const uint2 a = o0 >= 0 && o0 < lseq ? *(const uint2 *)(q + o0) : make_uint2(0u, 0u);
-        const uint2 b = o0 + 8 >= 0 && o0 + 8 < lseq ? *(const uint2 *)(q + o0 + 8) : make_uint2(0u, 0u);
+        uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+        if (o0 >= 0 && o0 < lseq) a = o0 < WV_QSTASH ? wv_lds8(wq + o0) : *(const uint2 *)(q + o0);
+        if (o0 + 8 >= 0 && o0 + 8 < lseq) b = o0 + 8 < WV_QSTASH ? wv_lds8(wq + o0 + 8) : *(const uint2 *)(q + o0 + 8);
         uint32_t fail = 0u;
 #define WV_STEP(B)                                                                                                        \
         {                                                                                                                     \
@@ -286,6 +291,7 @@ struct WaveSink {
     const EventBuf &eb;
     uint32_t read;
     lds_u32 *ev, *nev;
+    uint32_t ev_cap;      // events the wave's stage holds
     __device__ void add(int32_t r, uint32_t col) {
         const uint32_t d = (uint32_t)(r - base);
         if (d < win_n) lds_add(win + col * win_n + d, 1u);
@@ -293,7 +299,7 @@ struct WaveSink {
     }
     __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
         const uint32_t k = __hip_atomic_fetch_add(nev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k < (uint32_t)WV_EVCAP) {
+        if (k < ev_cap) {
             ev[k * 4] = (uint32_t)pos; ev[k * 4 + 1] = read; ev[k * 4 + 2] = (uint32_t)lo; ev[k * 4 + 3] = (uint32_t)hi;
             const uint32_t d = (uint32_t)(pos - base);
             if (d < win_n) lds_add(win + ev_plane * win_n + d, 1u);
@@ -305,10 +311,10 @@ struct WaveSink {
 };
 
 // the wave's staged events -> the block's shard of the list (one reservation)
-__device__ __forceinline__ void wv_flush_events(const EventBuf &eb, lds_u32 *ev, lds_u32 *nev, int lane) {
+__device__ __forceinline__ void wv_flush_events(const EventBuf &eb, lds_u32 *ev, lds_u32 *nev, uint32_t ev_cap, int lane) {
     wave_sync();
     const uint32_t staged = *nev;
-    const uint32_t n = staged < (uint32_t)WV_EVCAP ? staged : (uint32_t)WV_EVCAP;
+    const uint32_t n = staged < ev_cap ? staged : ev_cap;
     if (n == 0u) return;
     const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
     unsigned long long b0 = 0ull;
@@ -324,38 +330,75 @@ __device__ __forceinline__ void wv_flush_events(const EventBuf &eb, lds_u32 *ev,
 
 // One read on one wave: trims (A:426-687), outputs, counts (A:690-753).  x, y, z: the wave's three LDS rows of WV_MAXOPS
 // words.  Returns false -- with nothing written anywhere -- when the read is not one for this path.
+// The per-read fields, one per lane of a single load instruction (a wave that walks a list issues the load for its
+// next read before it starts on the current one).
+__device__ __forceinline__ uint32_t wv_header_load(const amp_dev_reads &rd, int64_t i, int lane) {
+    uint32_t h = 0u;
+    if (lane == 0) h = rd.cig_off32[i];
+    else if (lane == 1) h = rd.cig_off32[i + 1];
+    else if (lane == 2) h = rd.lseq[i];
+    else if (lane == 3) h = (uint32_t)rd.pos[i];
+    else if (lane == 4) h = rd.flag[i];
+    else if (lane == 5) h = (uint32_t)rd.tlen[i];
+    else if (lane == 6) h = rd.seq_off8[i];
+    return h;
+}
+__device__ __forceinline__ uint32_t wv_field(uint32_t h, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)h, k); }
+
 template <class Sink>
-__device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink, const EventBuf &eb,
-                          lds_u32 *x, lds_u32 *y, lds_u32 *z, int lane) {
-    const uint32_t c0 = rd.cig_off32[i];
-    int n = (int)(rd.cig_off32[i + 1] - c0);
-    const int32_t lseq = (int32_t)rd.lseq[i];
-    int32_t pos = rd.pos[i];
-    const uint32_t flag = rd.flag[i];
-    const int64_t boff = (int64_t)rd.seq_off8[i] * 8;
+__device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, uint32_t hdr, const DevOut &out, Sink &sink, const EventBuf &eb,
+                          lds_u32 *x, lds_u32 *y, lds_u32 *z, lds_u8 *wq, int max_ops, int lane) {
+    const uint32_t c0 = wv_field(hdr, 0);
+    int n = (int)(wv_field(hdr, 1) - c0);
+    const int32_t lseq = (int32_t)wv_field(hdr, 2);
+    int32_t pos = (int32_t)wv_field(hdr, 3);
+    const uint32_t flag = wv_field(hdr, 4);
+    const int64_t boff = (int64_t)wv_field(hdr, 6) * 8;
     const uint8_t *qual = rd.qual + boff;
-    if (n < 1 || n > WV_MAXOPS - 4 || lseq <= 0 || pos < 0 || P.window < 1 || P.window > 8) return false;
-    // ---- the ops into row x; is this a read for the closed forms?
+    if (n < 1 || n > max_ops || lseq <= 0 || pos < 0 || P.window < 1 || P.window > 8) return false;
+    // ---- everything the read needs from memory in one round trip: its ops (row x), the first 512 qualities (stash wq)
+    // and packed bases (kept in a register for the counting), the left primer table entry
+    uint32_t cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cw[c] = c * 64 + lane < n ? rd.cig[c0 + c * 64 + lane] : (1u << 4);
+    const int32_t q8l = lane * 8;
+    uint2 qq0 = make_uint2(0u, 0u), qtail = make_uint2(0u, 0u);
+    uint32_t sw0 = 0u;
+    if (q8l < lseq) { qq0 = *(const uint2 *)(qual + q8l); sw0 = *(const uint32_t *)(rd.seq + ((boff + q8l) >> 1)); }
+    if (lane == 0 && lseq > 512) qtail = *(const uint2 *)(qual + 512);
+    int32_t left_max_end = -1;
+    if (P.do_trim && (uint32_t)pos < (uint32_t)P.ref_len) left_max_end = P.max_end[pos];
     uint32_t qsum = 0u, rsum = 0u;
     bool dirty = false;
-    for (int c = 0; c < n; c += 64) {
-        const int k = c + lane;
-        const uint32_t v = k < n ? rd.cig[c0 + k] : (1u << 4), op = v & 15u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = c * 64 + lane;
+        const uint32_t v = cw[c], op = v & 15u;
         if (k < n) x[k] = v;
         dirty |= !((0x19Fu >> op) & 1u) || (v >> 4) == 0u;         // M I D N S = X, no empty op
         qsum += consumes_query(op) && k < n ? v >> 4 : 0u;
         rsum += consumes_ref(op) && k < n ? v >> 4 : 0u;
     }
+    for (int c = 256; c < n; c += 64) {
+        const int k = c + lane;
+        const uint32_t v = k < n ? rd.cig[c0 + k] : (1u << 4), op = v & 15u;
+        if (k < n) x[k] = v;
+        dirty |= !((0x19Fu >> op) & 1u) || (v >> 4) == 0u;
+        qsum += consumes_query(op) && k < n ? v >> 4 : 0u;
+        rsum += consumes_ref(op) && k < n ? v >> 4 : 0u;
+    }
+    *(lds_u32x2 *)(wq + q8l) = amp_u32x2{qq0.x, qq0.y};
+    if (lane == 0) *(lds_u32x2 *)(wq + 512) = amp_u32x2{qtail.x, qtail.y};
     qsum = wv_sum(qsum); rsum = wv_sum(rsum);
-    if (__ballot(dirty) || qsum != (uint32_t)lseq || qual[0] == 0xFFu) return false;
+    if (__ballot(dirty) || qsum != (uint32_t)lseq || ((uint32_t)__builtin_amdgcn_readfirstlane((int)qq0.x) & 0xFFu) == 0xFFu) return false;   // QUAL '*'
     wave_sync();
     uint32_t tflags = 0u;
     if (P.do_trim) {
         const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
         const int32_t re1 = pos + (int32_t)(rsum ? rsum : 1u) - 1;
         if ((uint32_t)pos >= (uint32_t)P.ref_len || (uint32_t)re1 >= (uint32_t)P.ref_len) return false;     // A:450-451 raise
-        const int32_t left_max_end = P.max_end[pos], right_min_start = P.min_start[re1];
-        const int32_t tl = rd.tlen[i], at = tl < 0 ? -tl : tl;
+        const int32_t right_min_start = P.min_start[re1];
+        const int32_t tl = (int32_t)wv_field(hdr, 5), at = tl < 0 ? -tl : tl;
         const bool isize_flag = ((int64_t)at - P.max_primer_len) > (int64_t)lseq;                            // A:452
         const bool do_left = !(is_paired && isize_flag && is_reverse) && left_max_end >= 0;                  // A:460
         const bool do_right = !(is_paired && isize_flag && !is_reverse) && right_min_start >= 0;             // A:517
@@ -401,7 +444,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         int32_t lo, hi;
         py_slice(qs, lseq - trail, lseq, lo, hi);
         const int32_t qlen = hi - lo;
-        const int32_t isc = wv_quality_scan(qual, lseq, lo, qlen, P.window, P.min_quality, is_reverse, lane);
+        const int32_t isc = wv_quality_scan(qual, wq, lseq, lo, qlen, P.window, P.min_quality, is_reverse, lane);
         if (is_reverse) {
             const int32_t del = isc;
             const int32_t sp = wv_pos_on_ref(x, n, del + qs - 1, pos, lane);                                 // A:591
@@ -467,8 +510,9 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
             for (int32_t q0 = 0; q0 < lseq; q0 += 512) {
                 const int32_t q8 = q0 + lane * 8;
                 if (q8 < lseq) {
-                    const uint2 qq = *(const uint2 *)(qual + q8);
-                    const uint32_t sw = *(const uint32_t *)(rd.seq + ((boff + q8) >> 1));
+                    uint2 qq = qq0;
+                    uint32_t sw = sw0;
+                    if (q0) { qq = *(const uint2 *)(qual + q8); sw = *(const uint32_t *)(rd.seq + ((boff + q8) >> 1)); }
                     // the op that holds base q8: the last one that starts at or before it
                     int lo_k = 0, hi_k = n - 1;
                     while (lo_k < hi_k) { const int mid = (lo_k + hi_k + 1) >> 1; if ((int32_t)y[mid] <= q8) lo_k = mid; else hi_k = mid - 1; }
@@ -497,7 +541,8 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
                 }
             }
             // deletions / reference skips and insertion runs: lane = op
-            const QualAt qf{qual};
+            const QualAt qglob{qual};
+            const auto qf = [&](int32_t q) -> uint32_t { return q < WV_QSTASH ? (uint32_t)wq[q] : qglob(q); };
             for (int c = 0; c < n; c += 64) {
                 const int k = c + lane;
                 if (k >= n) continue;
@@ -561,6 +606,83 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
     }
     wave_sync();
     return true;
+}
+
+// ---- the kernel of its own for batches made of such reads (Nanopore-like amplicon runs) -------------------------
+// The heavy pass gives a list segment to a block of four waves, two blocks per CU; with every read of a batch on
+// this path that is 8 reads in flight per CU, each a chain of dependent steps.  k_long runs 16 waves per CU (one
+// block; the trims need few registers) over the list of long reads that k_gcompact extracts from the general list
+// (entries flagged GL_LONG, which the tile kernel then skips).  A block takes chunks of L_CHUNK consecutive list
+// entries from a ticket counter -- neighbours on the reference: their counts meet in one LDS window that is
+// flushed per chunk --, a wave every 16th read of the chunk, with the header of its next read already on the way.
+// A read the closed forms do not take loses its flag: the general pass, launched behind this kernel, treats it.
+constexpr int L_WAVES = 16;
+constexpr int L_MAXOPS = 256;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops
+constexpr int L_EVCAP = 64;          // events staged per wave
+constexpr int L_CHUNK = 128;
+constexpr uint32_t L_WIN = 1024;     // reference positions of the block's window
+struct LongLds {
+    uint32_t win[(AMP_NSYM + 1) * L_WIN];
+    uint32_t rows[L_WAVES * 3 * L_MAXOPS];
+    uint32_t ev[L_WAVES * L_EVCAP * 4];
+    uint32_t wq[L_WAVES * 132];
+    uint32_t nev[L_WAVES];
+    uint32_t chunk;
+    int32_t base;
+};
+
+__global__ void __launch_bounds__(L_WAVES * 64)
+k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb,
+       const uint32_t *__restrict__ llist, const uint32_t *__restrict__ lpos, uint32_t *dense) {
+    __shared__ __attribute__((aligned(16))) LongLds L;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_long = (uint32_t)eb.ctr[26];            // left by k_gcompact
+    if (n_long == 0u) return;
+    for (uint32_t w = (uint32_t)tid; w < (AMP_NSYM + 1) * L_WIN; w += L_WAVES * 64) L.win[w] = 0u;
+    if (lane == 0) L.nev[wave] = 0u;
+    lds_u32 *const row = (lds_u32 *)L.rows + wave * (3 * L_MAXOPS);
+    lds_u32 *const wev = (lds_u32 *)L.ev + wave * (L_EVCAP * 4), *const wn = (lds_u32 *)&L.nev[wave];
+    lds_u8 *const wq = (lds_u8 *)((lds_u32 *)L.wq + wave * 132);
+    const uint32_t n_chunk = (n_long + L_CHUNK - 1) / L_CHUNK;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t c = (uint32_t)atomicAdd(&eb.ctr[27], 1ull);
+            L.chunk = c;
+            if (c < n_chunk) { const int32_t p = rd.pos[llist[(size_t)c * L_CHUNK]]; L.base = (p < 0 ? 0 : p) & ~31; }
+        }
+        __syncthreads();
+        const uint32_t ch = L.chunk;
+        if (ch >= n_chunk) break;
+        const int32_t base = L.base;
+        const uint32_t k1 = (ch + 1u) * L_CHUNK < n_long ? (ch + 1u) * L_CHUNK : n_long;
+        uint32_t k = ch * L_CHUNK + (uint32_t)wave;
+        int64_t i = 0;
+        uint32_t hdr = 0u;
+        if (k < k1) { i = (int64_t)llist[k]; hdr = wv_header_load(rd, i, lane); }
+        while (k < k1) {
+            const uint32_t kn = k + L_WAVES;
+            int64_t in = 0;
+            uint32_t hn = 0u;
+            if (kn < k1) { in = (int64_t)llist[kn]; hn = wv_header_load(rd, in, lane); }      // lands while this read is worked on
+            WaveSink ws{(lds_u32 *)L.win, base, L_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)L_EVCAP};
+            if (!wave_read(P, rd, i, hdr, out, ws, eb, row, row + L_MAXOPS, row + 2 * L_MAXOPS, wq, L_MAXOPS - 4, lane)) {
+                if (lane == 0) dense[lpos[k]] &= ~GL_LONG;
+            }
+            if (*wn > (uint32_t)L_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
+            k = kn; i = in; hdr = hn;
+        }
+        __syncthreads();
+        for (uint32_t w = (uint32_t)tid; w < (AMP_NSYM + 1) * L_WIN; w += L_WAVES * 64) {
+            const uint32_t v = L.win[w];
+            if (!v) continue;
+            L.win[w] = 0u;
+            const uint32_t plane = w / L_WIN, p = (uint32_t)base + w % L_WIN;
+            if (plane < AMP_NSYM) atomicAdd(&counts[(size_t)p * AMP_NSYM + plane], v);
+            else atomicAdd(&eb.ins_at[p], v);
+        }
+    }
+    wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
 }
 
 }  // namespace amp

@@ -326,7 +326,7 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
 constexpr int D_MAXOPS = 19;      // (with the rest of HeavyLds this lets two blocks share a CU's 160 KB)
-static_assert(4 * 3 * WV_MAXOPS <= 2 * D_MAXOPS * 256 && 4 * WV_EVCAP <= 512, "the wave path's rows and event stages alias the columns / the block's stage");
+static_assert(4 * (3 * WV_MAXOPS + 132) <= 2 * D_MAXOPS * 256 && 4 * WV_EVCAP <= 512 && WV_QSTASH <= 528, "the wave path's rows and event stages alias the columns / the block's stage");
 template <class CB, class Sink>
 __device__ bool process_read_full(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
                                   const EventBuf &eb, bool status_only, CB &cur, CB &tmp, uint32_t c0, int n,
@@ -619,15 +619,16 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
             const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
             lds_u32 *const row = (lds_u32 *)s_cig + wave * (3 * WV_MAXOPS);
             lds_u32 *const wev = (lds_u32 *)s_ev + wave * (WV_EVCAP * 4), *const wn = (lds_u32 *)&L.wnev[wave];
+            lds_u8 *const wq = (lds_u8 *)((lds_u32 *)s_cig + 4 * 3 * WV_MAXOPS + wave * 132);
             for (uint32_t c = (uint32_t)wave; c < nlong; c += 4u) {
                 const int64_t i = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.lng[c]);
-                WaveSink ws{(lds_u32 *)s_win, base, D_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn};
-                if (!wave_read(P, rd, i, out, ws, eb, row, row + WV_MAXOPS, row + 2 * WV_MAXOPS, lane)) {
+                WaveSink ws{(lds_u32 *)s_win, base, D_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)WV_EVCAP};
+                if (!wave_read(P, rd, i, wv_header_load(rd, i, lane), out, ws, eb, row, row + WV_MAXOPS, row + 2 * WV_MAXOPS, wq, WV_MAXOPS - 4, lane)) {
                     if (lane == 0) s_coop[atomicAdd(&L.nslow, 1u)] = (uint32_t)i;      // not a read for the closed forms
                 }
-                if (*wn > (uint32_t)WV_EVCAP / 2u) wv_flush_events(eb, wev, wn, lane);
+                if (*wn > (uint32_t)WV_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)WV_EVCAP, lane);
             }
-            wv_flush_events(eb, wev, wn, lane);
+            wv_flush_events(eb, wev, wn, (uint32_t)WV_EVCAP, lane);
             __syncthreads();
             const uint32_t nslow = L.nslow;
             for (uint32_t k = threadIdx.x; k < nslow; k += blockDim.x) {
@@ -1067,7 +1068,10 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const int64_t n_tiles_max = (n + TILE - 1) / TILE;
     const int64_t gen_tpb_max = (((n_tiles_max + gen_grid - 1) / gen_grid + T_WAVES - 1) / T_WAVES) * T_WAVES;
     const size_t dlist_words = std::max(((size_t)tg.grid + 1) * (size_t)tg.tpb, (size_t)(n_tiles_max + gen_tpb_max + T_WAVES)) * TILE;
-    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 : 0;
+    // a batch of reads with many CIGAR ops (eight a read on average: Nanopore-like) gets k_long (amp_wave.hpp) for them; the
+    // results do not depend on this choice
+    const bool long_kernel = variant == 4 && rd->n_cig >= 8 * n;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + (long_kernel ? 2 * (size_t)n : 0) : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
@@ -1101,8 +1105,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr);
+        uint32_t *llist = (uint32_t *)geo + 4, *lpos = llist + n;
+        if (long_kernel) HIPCHK(c, hipMemsetAsync(&c->d_ctr[26], 0, 2 * sizeof(unsigned long long), c->stream));      // its list length and chunk ticket
+        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr,
+                                                              rd->cig_off32, llist, lpos, long_kernel ? L_MAXOPS - 4 : 0);
         HIPCHK(c, hipGetLastError());
+        if (long_kernel) {
+            k_long<<<(unsigned)c->n_cu, L_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, llist, lpos, gdense);
+            HIPCHK(c, hipGetLastError());
+        }
 #ifdef AMP_DEV
         if (c->phases & 0x100u) {           // stamps of the general pass alone: the fast kernel's are dropped
             HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 12 * sizeof(unsigned long long), c->stream));
