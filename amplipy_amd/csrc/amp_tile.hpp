@@ -629,6 +629,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         bool valid = li < n;
         uint32_t lent = 0;
         if (LIST && valid) { lent = rlist[li]; if (lent & GL_LONG) valid = false; }
+        if (LIST && !__ballot(valid)) continue;            // a tile of reads that k_long took
         const int64_t i = LIST ? (int64_t)(lent & GL_INDEX_MASK) : li;
         const bool status_wanted = LIST && (lent & GL_STATUS_ONLY);      // the fast kernel counted it: exact status only
         int32_t lseq = 0, pos = 0, tlen = 0;

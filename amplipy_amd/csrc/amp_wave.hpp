@@ -32,6 +32,17 @@ __device__ __forceinline__ uint32_t wv_scan(uint32_t x) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return (uint32_t)v;
 }
+// inclusive prefix maximum (unsigned; 0 is the identity)
+__device__ __forceinline__ uint32_t wv_scan_max(uint32_t x) {
+    uint32_t v = x, t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = v > t ? v : t;
+    return v;
+}
 __device__ __forceinline__ uint32_t wv_last(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 __device__ __forceinline__ uint32_t wv_sum(uint32_t x) { return wv_last(wv_scan(x)); }
 
@@ -205,6 +216,8 @@ __device__ __forceinline__ int wv_merge(lds_u32 *u, int m, lds_u32 *z, lds_u32 *
 }
 
 constexpr int WV_QSTASH = 520;     // quality bytes of a read kept in the wave's LDS stash (512 + the 8 a forward window may reach into)
+// the wave's stash: [0, 528) qualities, [528, 784) the packed bases of the first 512, [784, 1040) 64 words for the base lanes' op marks
+constexpr int WV_STASH_WORDS = 260;
 __device__ __forceinline__ uint2 wv_lds8(const lds_u8 *p) { const amp_u32x2 v = *(const lds_u32x2 *)p; return make_uint2(v.x, v.y); }
 
 // 8 bytes starting at byte B (0..8) of the 16-byte group (a, b)
@@ -286,6 +299,9 @@ struct WaveSink {
     lds_u32 *win;
     int32_t base;
     uint32_t win_n;       // positions per plane of the window
+    uint32_t pitch;       // words per plane
+    uint32_t skew;        // 6: position d sits at word d + (d >> 6) of its plane; 31: no skew.  The 8-base lanes of a wave add at
+                          // positions 8 apart: without the skew lanes l and l + 8 (64 positions apart) share a bank, an 8-way conflict
     uint32_t ev_plane;    // plane index of the insertion-event tally
     uint32_t *counts;
     const EventBuf &eb;
@@ -294,7 +310,7 @@ struct WaveSink {
     uint32_t ev_cap;      // events the wave's stage holds
     __device__ void add(int32_t r, uint32_t col) {
         const uint32_t d = (uint32_t)(r - base);
-        if (d < win_n) lds_add(win + col * win_n + d, 1u);
+        if (d < win_n) lds_add(win + col * pitch + d + (d >> skew), 1u);
         else atomicAdd(&counts[(size_t)r * AMP_NSYM + col], 1u);
     }
     __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
@@ -302,7 +318,7 @@ struct WaveSink {
         if (k < ev_cap) {
             ev[k * 4] = (uint32_t)pos; ev[k * 4 + 1] = read; ev[k * 4 + 2] = (uint32_t)lo; ev[k * 4 + 3] = (uint32_t)hi;
             const uint32_t d = (uint32_t)(pos - base);
-            if (d < win_n) lds_add(win + ev_plane * win_n + d, 1u);
+            if (d < win_n) lds_add(win + ev_plane * pitch + d + (d >> skew), 1u);
             else atomicAdd(&eb.ins_at[pos], 1u);
         } else {
             eb.record(pos, read, lo, hi);
@@ -345,9 +361,16 @@ __device__ __forceinline__ uint32_t wv_header_load(const amp_dev_reads &rd, int6
 }
 __device__ __forceinline__ uint32_t wv_field(uint32_t h, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)h, k); }
 
+#ifdef AMP_WV_STAMPS
+__device__ unsigned long long g_wv_acc[8];
+#define WV_T(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); wv_tacc[k] += tn_ - tprev_; tprev_ = tn_; } while (0)
+#else
+#define WV_T(k) do { } while (0)
+#endif
 template <class Sink>
 __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, uint32_t hdr, const DevOut &out, Sink &sink, const EventBuf &eb,
-                          lds_u32 *x, lds_u32 *y, lds_u32 *z, lds_u8 *wq, int max_ops, int lane) {
+                          lds_u32 *x, lds_u32 *y, lds_u32 *z, lds_u8 *wq, int max_ops, int lane, unsigned long long *wv_tacc = nullptr) {
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime(); (void)tprev_;
     const uint32_t c0 = wv_field(hdr, 0);
     int n = (int)(wv_field(hdr, 1) - c0);
     const int32_t lseq = (int32_t)wv_field(hdr, 2);
@@ -388,10 +411,12 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         rsum += consumes_ref(op) && k < n ? v >> 4 : 0u;
     }
     *(lds_u32x2 *)(wq + q8l) = amp_u32x2{qq0.x, qq0.y};
+    *(lds_u32 *)(wq + 528 + lane * 4) = sw0;
     if (lane == 0) *(lds_u32x2 *)(wq + 512) = amp_u32x2{qtail.x, qtail.y};
     qsum = wv_sum(qsum); rsum = wv_sum(rsum);
     if (__ballot(dirty) || qsum != (uint32_t)lseq || ((uint32_t)__builtin_amdgcn_readfirstlane((int)qq0.x) & 0xFFu) == 0xFFu) return false;   // QUAL '*'
     wave_sync();
+    WV_T(0);
     uint32_t tflags = 0u;
     if (P.do_trim) {
         const bool is_paired = flag & 1u, is_reverse = (flag & 0x10u) != 0;
@@ -422,6 +447,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
             const int m = wv_primer_clip(x, n, true, del, y, lane, adv);
             n = wv_merge(y, m, z, x, true, lane);
         }
+        WV_T(1);
         // A:561 query_alignment_qualities of the clipped read: leading soft clips, trailing soft clips (element 0 is never
         // looked at from the back)
         int32_t qs = 0, trail = 0;
@@ -445,6 +471,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         py_slice(qs, lseq - trail, lseq, lo, hi);
         const int32_t qlen = hi - lo;
         const int32_t isc = wv_quality_scan(qual, wq, lseq, lo, qlen, P.window, P.min_quality, is_reverse, lane);
+        WV_T(2);
         if (is_reverse) {
             const int32_t del = isc;
             const int32_t sp = wv_pos_on_ref(x, n, del + qs - 1, pos, lane);                                 // A:591
@@ -462,6 +489,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
             }
         }
     }
+    WV_T(3);
     // ---- the final CIGAR: query / reference start of every op (rows y, z), shape
     int32_t qtot = 0, rtot = 0;
     int first_body = -1, last_body = -1, n_body = 0;
@@ -495,6 +523,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         if (out.ref_len) out.ref_len[i] = ref_len_final;
         if (out.trim_flags) out.trim_flags[i] = (uint8_t)tflags;
     }
+    WV_T(4);
     int err = 0;
     if (P.do_count) {
         const uint32_t G = (uint32_t)P.ref_len;
@@ -506,40 +535,47 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         } else if (n_body) {
             const int32_t ref_end = pos + ref_len_final;
             bool bad = false;
-            // match bases: lane = 8 consecutive query bases
-            for (int32_t q0 = 0; q0 < lseq; q0 += 512) {
-                const int32_t q8 = q0 + lane * 8;
-                if (q8 < lseq) {
-                    uint2 qq = qq0;
-                    uint32_t sw = sw0;
-                    if (q0) { qq = *(const uint2 *)(qual + q8); sw = *(const uint32_t *)(rd.seq + ((boff + q8) >> 1)); }
-                    // the op that holds base q8: the last one that starts at or before it
-                    int lo_k = 0, hi_k = n - 1;
-                    while (lo_k < hi_k) { const int mid = (lo_k + hi_k + 1) >> 1; if ((int32_t)y[mid] <= q8) lo_k = mid; else hi_k = mid - 1; }
-                    int k = lo_k;
-                    uint32_t v = x[k];
-                    int32_t left = (int32_t)y[k] + (int32_t)(v >> 4) - q8;          // bases of this op from q8 on
-                    int32_t r = (int32_t)z[k] + (q8 - (int32_t)y[k]);
-                    const int nb = lseq - q8 < 8 ? lseq - q8 : 8;
-                    for (int b = 0; b < nb; ++b) {
-                        while (left == 0) {                                           // next query-consuming op
-                            v = x[++k];
-                            if (consumes_query(v & 15u)) { left = (int32_t)(v >> 4); r = (int32_t)z[k]; }
-                        }
-                        if (is_match_op(v & 15u)) {
-                            const uint32_t qb = ((b & 4 ? qq.y : qq.x) >> ((b & 3) * 8)) & 0xFFu;
+            // match bases: lane = base, 64 consecutive query bases a turn.  The ops that start inside the turn's range mark their
+            // first base with their index; a running maximum over the lanes gives every base its op (the op that reaches
+            // in from the turn before is carried over).
+            {
+                lds_u32 *const mark = (lds_u32 *)(wq + 784);
+                const lds_u8 *const sq = wq + 528;
+                int kbase = 0;
+                uint32_t carry = 0u;
+                for (int32_t Q0 = 0; Q0 < lseq; Q0 += 64) {
+                    mark[lane] = 0u;
+                    for (;;) {
+                        const int k = kbase + lane;
+                        const int32_t yk = k < n ? (int32_t)y[k] : INT32_MAX;
+                        const bool inr = yk < Q0 + 64;
+                        if (inr && consumes_query(x[k] & 15u)) mark[yk - Q0] = (uint32_t)k + 1u;
+                        const unsigned long long m = __ballot(inr);
+                        if (m == ~0ull) { kbase += 64; continue; }
+                        kbase += __popcll(m);                 // (ops are sorted by their query start: the lanes inside form a prefix)
+                        break;
+                    }
+                    uint32_t v = mark[lane];
+                    if (lane == 0 && v == 0u) v = carry;
+                    v = wv_scan_max(v);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+                    const int32_t q = Q0 + lane;
+                    if (q < lseq) {
+                        const int idx = (int)v - 1;
+                        if (is_match_op(x[idx] & 15u)) {
+                            const uint32_t qb = q < WV_QSTASH ? (uint32_t)wq[q] : (uint32_t)qual[q];
                             if ((int32_t)qb >= mq) {                                                         // A:718
-                                const uint32_t byte = (sw >> ((b >> 1) * 8)) & 0xFFu;
-                                const uint32_t col = col_of_code((b & 1) ? (byte & 15u) : (byte >> 4));
+                                const uint32_t byte = q < 512 ? (uint32_t)sq[q >> 1] : (uint32_t)rd.seq[(boff + q) >> 1];
+                                const uint32_t col = col_of_code((q & 1) ? (byte & 15u) : (byte >> 4));
+                                const int32_t r = (int32_t)z[idx] + (q - (int32_t)y[idx]);
                                 if (col > 4u || (uint32_t)r >= G) bad = true;
                                 else sink.add(r, col);                                                       // A:751-753
                             }
-                            ++r;
                         }
-                        --left;
                     }
                 }
             }
+            WV_T(5);
             // deletions / reference skips and insertion runs: lane = op
             const QualAt qglob{qual};
             const auto qf = [&](int32_t q) -> uint32_t { return q < WV_QSTASH ? (uint32_t)wq[q] : qglob(q); };
@@ -591,6 +627,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
                     }
                 }
             }
+            WV_T(6);
             if (__ballot(bad)) {
                 // some pair cannot be counted: the exact walk names the first error in pair order
                 if (lane == 0) {
@@ -613,21 +650,26 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
 // this path that is 8 reads in flight per CU, each a chain of dependent steps.  k_long runs 16 waves per CU (one
 // block; the trims need few registers) over the list of long reads that k_gcompact extracts from the general list
 // (entries flagged GL_LONG, which the tile kernel then skips).  A block takes chunks of L_CHUNK consecutive list
-// entries from a ticket counter -- neighbours on the reference: their counts meet in one LDS window that is
-// flushed per chunk --, a wave every 16th read of the chunk, with the header of its next read already on the way.
+// entries from a ticket counter in memory -- neighbours on the reference: their counts meet in one LDS window that is
+// flushed per chunk --; its waves draw the chunk's reads from a ticket counter in LDS, each with the header of its next
+// read already on the way.
 // A read the closed forms do not take loses its flag: the general pass, launched behind this kernel, treats it.
+// (Measured alternatives: waves taking every 16th read of the chunk wait 19 % longer at the chunk's barrier; a block that
+// walks a contiguous 1/256 of the list with a moving window has fewer barriers but ran 0.76-2.2 ms from launch to launch
+// against 0.98 ms.)
 constexpr int L_WAVES = 16;
 constexpr int L_MAXOPS = 256;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops
 constexpr int L_EVCAP = 64;          // events staged per wave
 constexpr int L_CHUNK = 128;
 constexpr uint32_t L_WIN = 1024;     // reference positions of the block's window
+constexpr uint32_t L_PITCH = L_WIN + L_WIN / 64;   // words per plane (skewed: see WaveSink)
 struct LongLds {
-    uint32_t win[(AMP_NSYM + 1) * L_WIN];
+    uint32_t win[(AMP_NSYM + 1) * L_PITCH];
     uint32_t rows[L_WAVES * 3 * L_MAXOPS];
     uint32_t ev[L_WAVES * L_EVCAP * 4];
-    uint32_t wq[L_WAVES * 132];
+    uint32_t wq[L_WAVES * WV_STASH_WORDS];
     uint32_t nev[L_WAVES];
-    uint32_t chunk;
+    uint32_t chunk, ticket;
     int32_t base;
 };
 
@@ -638,35 +680,41 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_long = (uint32_t)eb.ctr[26];            // left by k_gcompact
     if (n_long == 0u) return;
-    for (uint32_t w = (uint32_t)tid; w < (AMP_NSYM + 1) * L_WIN; w += L_WAVES * 64) L.win[w] = 0u;
+    for (uint32_t w = (uint32_t)tid; w < (AMP_NSYM + 1) * L_PITCH; w += L_WAVES * 64) L.win[w] = 0u;
     if (lane == 0) L.nev[wave] = 0u;
     lds_u32 *const row = (lds_u32 *)L.rows + wave * (3 * L_MAXOPS);
     lds_u32 *const wev = (lds_u32 *)L.ev + wave * (L_EVCAP * 4), *const wn = (lds_u32 *)&L.nev[wave];
-    lds_u8 *const wq = (lds_u8 *)((lds_u32 *)L.wq + wave * 132);
+    lds_u8 *const wq = (lds_u8 *)((lds_u32 *)L.wq + wave * WV_STASH_WORDS);
     const uint32_t n_chunk = (n_long + L_CHUNK - 1) / L_CHUNK;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         __syncthreads();
         if (tid == 0) {
             const uint32_t c = (uint32_t)atomicAdd(&eb.ctr[27], 1ull);
-            L.chunk = c;
+            L.chunk = c; L.ticket = 0u;
             if (c < n_chunk) { const int32_t p = rd.pos[llist[(size_t)c * L_CHUNK]]; L.base = (p < 0 ? 0 : p) & ~31; }
         }
         __syncthreads();
         const uint32_t ch = L.chunk;
         if (ch >= n_chunk) break;
         const int32_t base = L.base;
-        const uint32_t k1 = (ch + 1u) * L_CHUNK < n_long ? (ch + 1u) * L_CHUNK : n_long;
-        uint32_t k = ch * L_CHUNK + (uint32_t)wave;
+        const uint32_t k0 = ch * L_CHUNK, k1 = k0 + L_CHUNK < n_long ? k0 + L_CHUNK : n_long;
+        const auto draw = [&]() -> uint32_t {
+            uint32_t t = 0u;
+            if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&L.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return k0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        };
+        uint32_t k = draw();
         int64_t i = 0;
         uint32_t hdr = 0u;
         if (k < k1) { i = (int64_t)llist[k]; hdr = wv_header_load(rd, i, lane); }
         while (k < k1) {
-            const uint32_t kn = k + L_WAVES;
+            const uint32_t kn = draw();
             int64_t in = 0;
             uint32_t hn = 0u;
             if (kn < k1) { in = (int64_t)llist[kn]; hn = wv_header_load(rd, in, lane); }      // lands while this read is worked on
-            WaveSink ws{(lds_u32 *)L.win, base, L_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)L_EVCAP};
-            if (!wave_read(P, rd, i, hdr, out, ws, eb, row, row + L_MAXOPS, row + 2 * L_MAXOPS, wq, L_MAXOPS - 4, lane)) {
+            WaveSink ws{(lds_u32 *)L.win, base, L_WIN, L_PITCH, 6u, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)L_EVCAP};
+            if (!wave_read(P, rd, i, hdr, out, ws, eb, row, row + L_MAXOPS, row + 2 * L_MAXOPS, wq, L_MAXOPS - 4, lane, tacc)) {
                 if (lane == 0) dense[lpos[k]] &= ~GL_LONG;
             }
             if (*wn > (uint32_t)L_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
@@ -674,15 +722,19 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         }
         __syncthreads();
         for (uint32_t w = (uint32_t)tid; w < (AMP_NSYM + 1) * L_WIN; w += L_WAVES * 64) {
-            const uint32_t v = L.win[w];
+            const uint32_t plane = w / L_WIN, d = w % L_WIN, at = plane * L_PITCH + d + (d >> 6);
+            const uint32_t v = L.win[at];
             if (!v) continue;
-            L.win[w] = 0u;
-            const uint32_t plane = w / L_WIN, p = (uint32_t)base + w % L_WIN;
+            L.win[at] = 0u;
+            const uint32_t p = (uint32_t)base + d;
             if (plane < AMP_NSYM) atomicAdd(&counts[(size_t)p * AMP_NSYM + plane], v);
             else atomicAdd(&eb.ins_at[p], v);
         }
     }
     wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
+#ifdef AMP_WV_STAMPS
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&eb.ctr[8 + k], tacc[k]);
+#endif
 }
 
 }  // namespace amp

@@ -326,7 +326,7 @@ __device__ void process_read_serial(const KParams &P, const amp_dev_reads &rd, i
 //     - returns true and leaves the final CIGAR in `cur`;
 //   * anything else: the exact serial walk.
 constexpr int D_MAXOPS = 19;      // (with the rest of HeavyLds this lets two blocks share a CU's 160 KB)
-static_assert(4 * (3 * WV_MAXOPS + 132) <= 2 * D_MAXOPS * 256 && 4 * WV_EVCAP <= 512 && WV_QSTASH <= 528, "the wave path's rows and event stages alias the columns / the block's stage");
+static_assert(4 * (3 * WV_MAXOPS + WV_STASH_WORDS) <= 2 * D_MAXOPS * 256 && 4 * WV_EVCAP <= 512 && WV_QSTASH <= 528, "the wave path's rows and event stages alias the columns / the block's stage");
 template <class CB, class Sink>
 __device__ bool process_read_full(const KParams &P, const amp_dev_reads &rd, int64_t i, const DevOut &out, Sink &sink,
                                   const EventBuf &eb, bool status_only, CB &cur, CB &tmp, uint32_t c0, int n,
@@ -619,11 +619,12 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
             const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
             lds_u32 *const row = (lds_u32 *)s_cig + wave * (3 * WV_MAXOPS);
             lds_u32 *const wev = (lds_u32 *)s_ev + wave * (WV_EVCAP * 4), *const wn = (lds_u32 *)&L.wnev[wave];
-            lds_u8 *const wq = (lds_u8 *)((lds_u32 *)s_cig + 4 * 3 * WV_MAXOPS + wave * 132);
+            lds_u8 *const wq = (lds_u8 *)((lds_u32 *)s_cig + 4 * 3 * WV_MAXOPS + wave * WV_STASH_WORDS);
+            unsigned long long dummy_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)dummy_acc;
             for (uint32_t c = (uint32_t)wave; c < nlong; c += 4u) {
                 const int64_t i = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.lng[c]);
-                WaveSink ws{(lds_u32 *)s_win, base, D_WIN, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)WV_EVCAP};
-                if (!wave_read(P, rd, i, wv_header_load(rd, i, lane), out, ws, eb, row, row + WV_MAXOPS, row + 2 * WV_MAXOPS, wq, WV_MAXOPS - 4, lane)) {
+                WaveSink ws{(lds_u32 *)s_win, base, D_WIN, D_WIN, 31u, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)WV_EVCAP};
+                if (!wave_read(P, rd, i, wv_header_load(rd, i, lane), out, ws, eb, row, row + WV_MAXOPS, row + 2 * WV_MAXOPS, wq, WV_MAXOPS - 4, lane, dummy_acc)) {
                     if (lane == 0) s_coop[atomicAdd(&L.nslow, 1u)] = (uint32_t)i;      // not a read for the closed forms
                 }
                 if (*wn > (uint32_t)WV_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)WV_EVCAP, lane);
