@@ -656,7 +656,8 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
 // A read the closed forms do not take loses its flag: the general pass, launched behind this kernel, treats it.
 // (Measured alternatives: waves taking every 16th read of the chunk wait 19 % longer at the chunk's barrier; a block that
 // walks a contiguous 1/256 of the list with a moving window has fewer barriers but ran 0.76-2.2 ms from launch to launch
-// against 0.98 ms.)
+// against 0.98 ms; two blocks of 12 waves per CU (77 registers) trim a third faster but count a half slower: 1.26 ms
+// against 1.03 ms for the whole pass.)
 constexpr int L_WAVES = 16;
 constexpr int L_MAXOPS = 256;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops
 constexpr int L_EVCAP = 64;          // events staged per wave
