@@ -272,6 +272,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     for (int i = tid; i < F_BPL * F_BW; i += F_WAVES * 64) bwin[i] = 0;
     for (int i = lane; i < F_REP * F_REPW; i += 64) pwin[i] = 0;
     if (tid == 0) { s_ticket = 0; s_gcur = 0; }
+    if (tid == 0 && blockIdx.x == 0) { eb.ctr[26] = 0ull; eb.ctr[27] = 0ull; eb.ctr[28] = 0ull; }      // k_gcompact / k_long's counters (amp_wave.hpp)
     // the block's window: anchored 16 positions left of its first read (sorted input: nothing of this block starts
     // left of that read)
     int32_t bw_base = rb < n ? rd.pos[rb] : 0;
@@ -928,6 +929,7 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
         if ((tid & 63) == 0) s_lw[tid >> 6] = mine;
         __syncthreads();
         const uint32_t total = s_lw[0] + s_lw[1] + s_lw[2] + s_lw[3];
+        if (tid == 0 && cnt > total) atomicAdd(&ctr[28], (unsigned long long)(cnt - total));      // entries left to the tile kernel
         if (total) {                                   // (uniform over the block)
             if (tid == 0) s_lbase = (uint32_t)atomicAdd(&ctr[26], (unsigned long long)total);
             uint32_t run = 0;
@@ -955,7 +957,7 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
         uint32_t tpb = (tiles + gen_grid - 1) / gen_grid;
         tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;
         if (tpb < (uint32_t)T_WAVES) tpb = T_WAVES;
-        geo->n_list = n_list; geo->tpb = tpb; geo->n_seg = (tiles + tpb - 1) / tpb; geo->pad = 0;
+        geo->n_list = n_list; geo->tpb = tpb; geo->n_seg = (tiles + tpb - 1) / tpb; geo->live_counted = long_max_ops ? 1u : 0u;
         ctr[7] = n_list;                          // (amp_debug_counters: reads of the last batch that took the general pass)
     }
 }

@@ -67,7 +67,7 @@ struct GenGeo {            // geometry of the general pass, decided on the devic
     uint32_t n_list;       // entries of the dense list
     uint32_t tpb;          // tiles per block of k_tile<LIST>
     uint32_t n_seg;        // its blocks that have tiles
-    uint32_t pad;
+    uint32_t live_counted; // 1: ctr[28] holds the entries not flagged GL_LONG (k_long's batches); the tile kernel leaves at once when there are none
 };
 
 // per-read state words kept in LDS for the chunk lanes
@@ -571,7 +571,10 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_block;
     const int64_t tile_end = tile_begin + tiles_per_block < n_tiles ? tile_begin + tiles_per_block : n_tiles;
-    if (tile_begin >= tile_end) { if (threadIdx.x == 0) { dcnt[blockIdx.x] = 0; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = 0; } return; }
+    if (tile_begin >= tile_end || (LIST && geo->live_counted && ctr[28] == 0ull)) {
+        if (threadIdx.x == 0) { dcnt[blockIdx.x] = 0; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = 0; }
+        return;
+    }
 
     lds_u32 *const win = (lds_u32 *)L.win;
     lds_u32 *const lut = (lds_u32 *)L.lut;

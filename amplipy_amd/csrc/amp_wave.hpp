@@ -716,7 +716,7 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (kn < k1) { in = (int64_t)llist[kn]; hn = wv_header_load(rd, in, lane); }      // lands while this read is worked on
             WaveSink ws{(lds_u32 *)L.win, base, L_WIN, L_PITCH, 6u, (uint32_t)AMP_NSYM, counts, eb, (uint32_t)(read_base + (uint64_t)i), wev, wn, (uint32_t)L_EVCAP};
             if (!wave_read(P, rd, i, hdr, out, ws, eb, row, row + L_MAXOPS, row + 2 * L_MAXOPS, wq, L_MAXOPS - 4, lane, tacc)) {
-                if (lane == 0) dense[lpos[k]] &= ~GL_LONG;
+                if (lane == 0) { dense[lpos[k]] &= ~GL_LONG; atomicAdd(&eb.ctr[28], 1ull); }
             }
             if (*wn > (uint32_t)L_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
             k = kn; i = in; hdr = hn;

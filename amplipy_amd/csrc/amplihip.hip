@@ -1107,7 +1107,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         }
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         uint32_t *llist = (uint32_t *)geo + 4, *lpos = llist + n;
-        if (long_kernel) HIPCHK(c, hipMemsetAsync(&c->d_ctr[26], 0, 2 * sizeof(unsigned long long), c->stream));      // its list length and chunk ticket
+        // (ctr[26..28] -- k_long's list length, its chunk ticket, the entries left to the tile kernel -- are zeroed by the fast kernel)
         k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr,
                                                               rd->cig_off32, llist, lpos, long_kernel ? L_MAXOPS - 4 : 0);
         HIPCHK(c, hipGetLastError());
