@@ -344,6 +344,30 @@ __device__ __forceinline__ void wv_flush_events(const EventBuf &eb, lds_u32 *ev,
     wave_sync();
 }
 
+// The same for a wave that owns a GRANULE of `cap` list slots reserved ahead of time (k_long): the staged events go into it
+// at once, the rest of the granule is marked unused (ref_pos = -1, dropped when the list is read out) and the next
+// granule is asked for -- its first slot is still on its way from the atomic when this returns and is only looked at by
+// the next flush, so the wave never waits for the list cursor (a flush with a returning atomic cost the wave a few
+// microseconds; halving their number took the many-op pass from 1.26 to 0.85 ms).  gran: lane 0 holds the granule's
+// first slot.  more = false: the last flush of the wave, no further granule.
+__device__ __forceinline__ void wv_flush_events_granule(const EventBuf &eb, lds_u32 *ev, lds_u32 *nev, uint32_t cap, int lane,
+                                                        unsigned long long &gran, bool more) {
+    wave_sync();
+    const uint32_t staged = *nev;
+    const uint32_t n = staged < cap ? staged : cap;
+    const unsigned shard = blockIdx.x & (EV_SHARDS - 1);
+    const unsigned long long b0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(gran >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)gran);
+    for (uint32_t k = (uint32_t)lane; k < cap; k += 64u)
+        if ((long long)(b0 + k) < eb.cap)
+            eb.ev[(size_t)shard * (size_t)eb.cap + b0 + k] =
+                k < n ? amp_ins_event{(int32_t)ev[k * 4], ev[k * 4 + 1], (int32_t)ev[k * 4 + 2], (int32_t)ev[k * 4 + 3]} : amp_ins_event{-1, 0u, 0, 0};
+    wave_sync();
+    if (lane == 0) *nev = 0u;
+    wave_sync();
+    if (more && lane == 0) gran = atomicAdd(&eb.ctr[16 + shard], (unsigned long long)cap);
+}
+
 // One read on one wave: trims (A:426-687), outputs, counts (A:690-753).  x, y, z: the wave's three LDS rows of WV_MAXOPS
 // words.  Returns false -- with nothing written anywhere -- when the read is not one for this path.
 // The per-read fields, one per lane of a single load instruction (a wave that walks a list issues the load for its
@@ -647,19 +671,20 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
 
 // ---- the kernel of its own for batches made of such reads (Nanopore-like amplicon runs) -------------------------
 // The heavy pass gives a list segment to a block of four waves, two blocks per CU; with every read of a batch on
-// this path that is 8 reads in flight per CU, each a chain of dependent steps.  k_long runs 16 waves per CU (one
-// block; the trims need few registers) over the list of long reads that k_gcompact extracts from the general list
-// (entries flagged GL_LONG, which the tile kernel then skips).  A block takes chunks of L_CHUNK consecutive list
+// this path that is 8 reads in flight per CU, each a chain of dependent steps.  k_long runs 24 waves per CU (two
+// blocks of twelve; the trims need 77 registers) over the list of long reads that k_gcompact extracts from the general
+// list (entries flagged GL_LONG, which the tile kernel then skips).  A block takes chunks of L_CHUNK consecutive list
 // entries from a ticket counter in memory -- neighbours on the reference: their counts meet in one LDS window that is
 // flushed per chunk --; its waves draw the chunk's reads from a ticket counter in LDS, each with the header of its next
 // read already on the way.
 // A read the closed forms do not take loses its flag: the general pass, launched behind this kernel, treats it.
-// (Measured alternatives: waves taking every 16th read of the chunk wait 19 % longer at the chunk's barrier; a block that
-// walks a contiguous 1/256 of the list with a moving window has fewer barriers but ran 0.76-2.2 ms from launch to launch
-// against 0.98 ms; two blocks of 12 waves per CU (77 registers) trim a third faster but count a half slower: 1.26 ms
-// against 1.03 ms for the whole pass.)
-constexpr int L_WAVES = 16;
-constexpr int L_MAXOPS = 256;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops
+// (Measured on 200,000 reads of 45 ops: one block of 16 waves per CU 0.99 ms for the whole pass, two blocks of 12 waves
+// 0.85 ms -- but 1.26 ms with event stages of 32 instead of 64: every flush of a stage is a returning atomic on the list
+// cursor that the wave waits for; waves taking every 16th read of the chunk wait 19 % longer at the chunk's barrier than
+// with the LDS ticket; a block that walks a contiguous 1/256 of the list with a moving window has fewer barriers but ran
+// 0.76-2.2 ms from launch to launch.)
+constexpr int L_WAVES = 12;
+constexpr int L_MAXOPS = 160;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops (more: the heavy pass's wave path, 508)
 constexpr int L_EVCAP = 64;          // events staged per wave
 constexpr int L_CHUNK = 128;
 constexpr uint32_t L_WIN = 1024;     // reference positions of the block's window
@@ -674,7 +699,7 @@ struct LongLds {
     int32_t base;
 };
 
-__global__ void __launch_bounds__(L_WAVES * 64)
+__global__ void __launch_bounds__(L_WAVES * 64, 6)
 k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb,
        const uint32_t *__restrict__ llist, const uint32_t *__restrict__ lpos, uint32_t *dense) {
     __shared__ __attribute__((aligned(16))) LongLds L;
@@ -687,6 +712,8 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const wev = (lds_u32 *)L.ev + wave * (L_EVCAP * 4), *const wn = (lds_u32 *)&L.nev[wave];
     lds_u8 *const wq = (lds_u8 *)((lds_u32 *)L.wq + wave * WV_STASH_WORDS);
     const uint32_t n_chunk = (n_long + L_CHUNK - 1) / L_CHUNK;
+    unsigned long long gran = 0ull;                          // the wave's granule of the event list (lane 0)
+    if (lane == 0) gran = atomicAdd(&eb.ctr[16 + (blockIdx.x & (EV_SHARDS - 1))], (unsigned long long)L_EVCAP);
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         __syncthreads();
@@ -718,7 +745,8 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             if (!wave_read(P, rd, i, hdr, out, ws, eb, row, row + L_MAXOPS, row + 2 * L_MAXOPS, wq, L_MAXOPS - 4, lane, tacc)) {
                 if (lane == 0) { dense[lpos[k]] &= ~GL_LONG; atomicAdd(&eb.ctr[28], 1ull); }
             }
-            if (*wn > (uint32_t)L_EVCAP / 2u) wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
+            // (a read of this kind records about ten events; one that overflows the stage records the rest one by one)
+            if (*wn > (uint32_t)L_EVCAP - 24u) wv_flush_events_granule(eb, wev, wn, (uint32_t)L_EVCAP, lane, gran, true);
             k = kn; i = in; hdr = hn;
         }
         __syncthreads();
@@ -732,7 +760,7 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             else atomicAdd(&eb.ins_at[p], v);
         }
     }
-    wv_flush_events(eb, wev, wn, (uint32_t)L_EVCAP, lane);
+    wv_flush_events_granule(eb, wev, wn, (uint32_t)L_EVCAP, lane, gran, false);
 #ifdef AMP_WV_STAMPS
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&eb.ctr[8 + k], tacc[k]);
 #endif

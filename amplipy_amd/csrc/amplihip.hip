@@ -1047,7 +1047,8 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // any shard may receive every new event; the fast kernel reserves list slots a granule at a time (a refill
         // leaves fewer slots unused than the tile that caused it needs, plus one open granule per wave at the end)
         const FastGrid fgb = fast_grid(n, c->n_cu);
-        const int64_t need = (int64_t)(mx + 2 * h[1]) + fgb.grid * F_WAVES * (int64_t)F_EVGRAN;
+        // (k_long's waves own granules too: amp_wave.hpp)
+        const int64_t need = (int64_t)(mx + 2 * h[1]) + fgb.grid * F_WAVES * (int64_t)F_EVGRAN + 2 * (int64_t)c->n_cu * L_WAVES * L_EVCAP;
         if (need > c->ev_cap) HIPCHK(c, grow_events(c, std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2)));
     }
     KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end};
@@ -1112,7 +1113,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
                                                               rd->cig_off32, llist, lpos, long_kernel ? L_MAXOPS - 4 : 0);
         HIPCHK(c, hipGetLastError());
         if (long_kernel) {
-            k_long<<<(unsigned)c->n_cu, L_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, llist, lpos, gdense);
+            k_long<<<2u * (unsigned)c->n_cu, L_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, llist, lpos, gdense);
             HIPCHK(c, hipGetLastError());
         }
 #ifdef AMP_DEV

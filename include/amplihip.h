@@ -224,8 +224,8 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * a small bound kernel and synchronises to size the buffer; with it the call is fully
  * asynchronous and amp_get_ins_events reports AMP_EOVERFLOW if the reservation was short.
  * `cap` is per list shard (there are 8, and any of them may receive most of a batch's events); size it for twice the
- * events of a batch plus 64 slots per wave of the fast kernel (8 per CU): waves reserve list slots 64 at a time and
- * leave some unused (read-out drops them). */
+ * events of a batch plus 64 slots per wave of the fast kernel (8 per CU) and of the many-op kernel (24 per CU): waves
+ * reserve list slots 64 at a time and leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
 /* 4 (default) = the fast kernel (closed-form trim + pileup of reads with one match op or one insertion / deletion, every byte
  * loaded once) followed by the general pass over the reads it hands over; 2 = the fused tile kernel over every read; 1 =
