@@ -570,6 +570,13 @@ def test_many_op_reads_of_every_shape(runner, seed, mq, w):
     assert len(ok) > 0.5 * len(segs)
     good = ReadBatch.from_segments([segs[i] for i in ok])
     assert_same(oracle.process(good, G, mn, mx, mpl, mq, w), runner.process(good, G, mn, mx, mpl, mq, w), good)
+    if seed <= 2:
+        # the untrimmed pile-up (A:915 without A:907) and the trims alone
+        a = oracle.process(b, G, mn, mx, mpl, mq, w, do_trim=False)
+        ok = np.nonzero(a.trim.status == 0)[0]
+        good = ReadBatch.from_segments([segs[i] for i in ok])
+        assert_same(oracle.process(good, G, mn, mx, mpl, mq, w, do_trim=False), runner.process(good, G, mn, mx, mpl, mq, w, do_trim=False), good)
+        assert_same(oracle.process(b, G, mn, mx, mpl, mq, w, do_count=False), runner.process(b, G, mn, mx, mpl, mq, w, do_count=False), b, check_counts=False)
 
 
 def test_single_rank_rccl_paths(tmp_path, scheme, monkeypatch):
