@@ -686,7 +686,7 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
 constexpr int L_WAVES = 12;
 constexpr int L_MAXOPS = 160;        // words per CIGAR row: reads of up to L_MAXOPS - 4 ops (more: the heavy pass's wave path, 508)
 constexpr int L_EVCAP = 64;          // events staged per wave
-constexpr int L_CHUNK = 128;
+constexpr int L_CHUNK = 128;         // most list entries a block takes at a time
 constexpr uint32_t L_WIN = 1024;     // reference positions of the block's window
 constexpr uint32_t L_PITCH = L_WIN + L_WIN / 64;   // words per plane (skewed: see WaveSink)
 struct LongLds {
@@ -711,7 +711,14 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const row = (lds_u32 *)L.rows + wave * (3 * L_MAXOPS);
     lds_u32 *const wev = (lds_u32 *)L.ev + wave * (L_EVCAP * 4), *const wn = (lds_u32 *)&L.nev[wave];
     lds_u8 *const wq = (lds_u8 *)((lds_u32 *)L.wq + wave * WV_STASH_WORDS);
-    const uint32_t n_chunk = (n_long + L_CHUNK - 1) / L_CHUNK;
+    // chunk sizes: at least four chunks a block, at most L_CHUNK entries; the last quarter of the list goes out in chunks a
+    // quarter that size, so that the blocks still busy at the end are busy with little (with 128 everywhere and three
+    // chunks a block, the few blocks that drew a fourth chunk set the kernel's duration)
+    uint32_t big = n_long / (4u * gridDim.x);
+    big = big > (uint32_t)L_CHUNK ? (uint32_t)L_CHUNK : big < 16u ? 16u : big;
+    const uint32_t small = big / 4u < 16u ? 16u : big / 4u;
+    const uint32_t n_bigc = (uint32_t)(((unsigned long long)n_long * 3ull / 4ull) / big), rest0 = n_bigc * big;
+    const uint32_t n_chunk = n_bigc + (n_long - rest0 + small - 1u) / small;
     unsigned long long gran = 0ull;                          // the wave's granule of the event list (lane 0)
     if (lane == 0) gran = atomicAdd(&eb.ctr[16 + (blockIdx.x & (EV_SHARDS - 1))], (unsigned long long)L_EVCAP);
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -720,13 +727,14 @@ k_long(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         if (tid == 0) {
             const uint32_t c = (uint32_t)atomicAdd(&eb.ctr[27], 1ull);
             L.chunk = c; L.ticket = 0u;
-            if (c < n_chunk) { const int32_t p = rd.pos[llist[(size_t)c * L_CHUNK]]; L.base = (p < 0 ? 0 : p) & ~31; }
+            if (c < n_chunk) { const int32_t p = rd.pos[llist[c < n_bigc ? c * big : rest0 + (c - n_bigc) * small]]; L.base = (p < 0 ? 0 : p) & ~31; }
         }
         __syncthreads();
         const uint32_t ch = L.chunk;
         if (ch >= n_chunk) break;
         const int32_t base = L.base;
-        const uint32_t k0 = ch * L_CHUNK, k1 = k0 + L_CHUNK < n_long ? k0 + L_CHUNK : n_long;
+        const uint32_t k0 = ch < n_bigc ? ch * big : rest0 + (ch - n_bigc) * small;
+        const uint32_t k1e = k0 + (ch < n_bigc ? big : small), k1 = k1e < n_long ? k1e : n_long;
         const auto draw = [&]() -> uint32_t {
             uint32_t t = 0u;
             if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&L.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
