@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (each has its own stream, engine and outputs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
+    ap.add_argument("--no-comm-overlap", action="store_true", help="multi-rank runs: all-reduce on the work stream, in front of the step's calls (default: on its own stream, under the next step's reads)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +116,10 @@ def main():
     # order (with a stream per step the small calling kernels of step k had to wait for a CU behind the blocks of the
     # next step's reads, which fill every CU), and the host assembles step k's records while reads(k+1) run
     work_stream = torch.cuda.Stream(device=dev)
+    # multi-rank runs: the step's one collective goes to a stream of its own.  xGMI moves the 0.8 MB table while the work
+    # stream already runs the next step's reads (other slot, other table); the step's calls are queued behind those reads
+    # and wait for the reduced table through an event.  One step of latency, no idle GPU around the collective.
+    comm_stream = torch.cuda.Stream(device=dev) if (dist is not None and not args.no_comm_overlap and not args.no_pipeline and args.in_flight > 1) else None
 
     class Slot:
         """One in-flight step: its own engine (device table, event list, scratch, pinned result image) and outputs."""
@@ -141,6 +146,8 @@ def main():
             }
             self.dev_out = abi.AmpTrimOut(*[self.out[k].data_ptr() for k in
                                             ("new_pos", "new_ncig", "new_cig", "ref_len", "trim_flags", "status")])
+            self.ev_reads, self.ev_reduced = torch.cuda.Event(), torch.cuda.Event()
+            self.call_due = False        # reads and all-reduce are queued, the calls are not yet
 
         def ins_provider(self, positions):
             eng = self.eng
@@ -156,23 +163,44 @@ def main():
     # records of step k-1.  Every step is complete -
     # kernels, reduce, calls, records, consensus string - before the timed region ends.
     depth = 1 if args.no_pipeline else max(1, args.in_flight)
+    if comm_stream is not None:
+        depth += 1        # the calls of a step are queued one step later: one more step in flight keeps the host's record assembly under the GPU's work
     slots = [Slot() for _ in range(depth)]
     pass_ms, fast_ms = [], []
     last = {}
+
+    def begin_calls(sl):
+        if sl.call_due:
+            with torch.cuda.stream(sl.stream):
+                sl.stream.wait_event(sl.ev_reduced)
+                sl.eng.call_compact_begin(cp)
+            sl.call_due = False
 
     def submit(k):
         sl = slots[k % depth]
         with torch.cuda.stream(sl.stream):
             sl.eng.reset()
             sl.eng.process_device(rd, 0, sl.dev_out)
-            if dist is not None:
-                # ONE collective per step: afterwards every rank holds the whole job's table and makes the same calls
+            if comm_stream is None:
+                if dist is not None:
+                    # ONE collective per step: afterwards every rank holds the whole job's table and makes the same calls
+                    parallel.allreduce_table(dist, sl.table)
+                # the calling kernels go in right behind: queued in front of the next step's reads, not behind them
+                sl.eng.call_compact_begin(cp)
+            else:
+                sl.ev_reads.record(sl.stream)
+        if comm_stream is not None:
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(sl.ev_reads)
                 parallel.allreduce_table(dist, sl.table)
-            # the calling kernels go in right behind: queued in front of the next step's reads, not behind them
-            sl.eng.call_compact_begin(cp)
+                sl.ev_reduced.record(comm_stream)
+            sl.call_due = True
+            # the calls of the step before: behind this step's reads on the work stream, its all-reduce ran under them
+            begin_calls(slots[(k - 1) % depth])
 
     def finish(k):
         sl = slots[k % depth]
+        begin_calls(sl)                  # (the last steps of a run have no later submit to do it)
         with torch.cuda.stream(sl.stream):
             last["call"] = res = calling.call(sl.eng, ref_seq, cp, sl.ins_provider)
             last["consensus"] = res.consensus_string("N")
@@ -188,7 +216,8 @@ def main():
         for k in range(max(n - (depth - 1), 0), n):
             finish(k)
 
-    run(args.warmup)
+    # every slot runs once before the timed region whatever W is (first use allocates: pinned result image, event list, scratch)
+    run(max(args.warmup, depth))
     del pass_ms[:], fast_ms[:]
     if dist is not None:
         dist.barrier()
@@ -334,7 +363,7 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
                        "parallelism": "coordinate-range partition x%d + one RCCL all-reduce of the count table per step" % world,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
-                       "steps_in_flight": depth, "kernel_variant": args.variant, "error_reads": n_err,
+                       "steps_in_flight": depth, "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
                        "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant,
                        "strong_check": strong_check},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
