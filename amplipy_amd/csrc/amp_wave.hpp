@@ -216,8 +216,8 @@ __device__ __forceinline__ int wv_merge(lds_u32 *u, int m, lds_u32 *z, lds_u32 *
 }
 
 constexpr int WV_QSTASH = 520;     // quality bytes of a read kept in the wave's LDS stash (512 + the 8 a forward window may reach into)
-// the wave's stash: [0, 528) qualities, [528, 784) the packed bases of the first 512, [784, 1040) 64 words for the base lanes' op marks
-constexpr int WV_STASH_WORDS = 260;
+// the wave's stash: [0, 528) qualities, [528, 784) the packed bases of the first 512, [784, 1296) 256 16-bit op marks of the base lanes
+constexpr int WV_STASH_WORDS = 324;
 __device__ __forceinline__ uint2 wv_lds8(const lds_u8 *p) { const amp_u32x2 v = *(const lds_u32x2 *)p; return make_uint2(v.x, v.y); }
 
 // 8 bytes starting at byte B (0..8) of the 16-byte group (a, b)
@@ -559,42 +559,60 @@ __device__ bool wave_read(const KParams &P, const amp_dev_reads &rd, int64_t i, 
         } else if (n_body) {
             const int32_t ref_end = pos + ref_len_final;
             bool bad = false;
-            // match bases: lane = base, 64 consecutive query bases a turn.  The ops that start inside the turn's range mark their
-            // first base with their index; a running maximum over the lanes gives every base its op (the op that reaches
-            // in from the turn before is carried over).
+            // match bases: lane = base, 256 consecutive query bases a turn (four per lane, 64 apart).  The ops that start inside
+            // the turn's range mark their first base with their index; a running maximum over the bases gives every base its op
+            // (the op that reaches in from the bases before is carried over).  All LDS reads of a step are issued together:
+            // the turn is a handful of dependent LDS round trips, not one chain per 64 bases.
             {
-                lds_u32 *const mark = (lds_u32 *)(wq + 784);
+                lds_u16 *const mark = (lds_u16 *)(wq + 784);
                 const lds_u8 *const sq = wq + 528;
                 int kbase = 0;
                 uint32_t carry = 0u;
-                for (int32_t Q0 = 0; Q0 < lseq; Q0 += 64) {
-                    mark[lane] = 0u;
+                for (int32_t Q0 = 0; Q0 < lseq; Q0 += 256) {
+                    *(lds_u32x2 *)(mark + lane * 4) = amp_u32x2{0u, 0u};
                     for (;;) {
                         const int k = kbase + lane;
                         const int32_t yk = k < n ? (int32_t)y[k] : INT32_MAX;
-                        const bool inr = yk < Q0 + 64;
-                        if (inr && consumes_query(x[k] & 15u)) mark[yk - Q0] = (uint32_t)k + 1u;
+                        const bool inr = yk < Q0 + 256;
+                        if (inr && consumes_query(x[k] & 15u)) mark[yk - Q0] = (uint16_t)(k + 1);
                         const unsigned long long m = __ballot(inr);
                         if (m == ~0ull) { kbase += 64; continue; }
                         kbase += __popcll(m);                 // (ops are sorted by their query start: the lanes inside form a prefix)
                         break;
                     }
-                    uint32_t v = mark[lane];
-                    if (lane == 0 && v == 0u) v = carry;
-                    v = wv_scan_max(v);
-                    carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-                    const int32_t q = Q0 + lane;
-                    if (q < lseq) {
-                        const int idx = (int)v - 1;
-                        if (is_match_op(x[idx] & 15u)) {
-                            const uint32_t qb = q < WV_QSTASH ? (uint32_t)wq[q] : (uint32_t)qual[q];
-                            if ((int32_t)qb >= mq) {                                                         // A:718
-                                const uint32_t byte = q < 512 ? (uint32_t)sq[q >> 1] : (uint32_t)rd.seq[(boff + q) >> 1];
-                                const uint32_t col = col_of_code((q & 1) ? (byte & 15u) : (byte >> 4));
-                                const int32_t r = (int32_t)z[idx] + (q - (int32_t)y[idx]);
-                                if (col > 4u || (uint32_t)r >= G) bad = true;
-                                else sink.add(r, col);                                                       // A:751-753
-                            }
+                    uint32_t v[4], qb[4], sb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int32_t q = Q0 + r * 64 + lane;
+                        v[r] = mark[r * 64 + lane];
+                        qb[r] = 0u; sb[r] = 0u;
+                        if (q < lseq) {
+                            qb[r] = q < WV_QSTASH ? (uint32_t)wq[q] : (uint32_t)qual[q];
+                            sb[r] = q < 512 ? (uint32_t)sq[q >> 1] : (uint32_t)rd.seq[(boff + q) >> 1];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = wv_scan_max(v[r]);
+                        v[r] = v[r] > carry ? v[r] : carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)v[r], 63);
+                    }
+                    uint32_t w[4];
+                    int32_t rr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int32_t q = Q0 + r * 64 + lane;
+                        const int idx = (int)v[r] - 1;
+                        w[r] = 15u; rr[r] = 0;
+                        if (q < lseq) { w[r] = x[idx]; rr[r] = (int32_t)z[idx] + (q - (int32_t)y[idx]); }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int32_t q = Q0 + r * 64 + lane;
+                        if (q < lseq && is_match_op(w[r] & 15u) && (int32_t)qb[r] >= mq) {                    // A:718
+                            const uint32_t col = col_of_code((q & 1) ? (sb[r] & 15u) : (sb[r] >> 4));
+                            if (col > 4u || (uint32_t)rr[r] >= G) bad = true;
+                            else sink.add(rr[r], col);                                                       // A:751-753
                         }
                     }
                 }
