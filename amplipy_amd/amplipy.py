@@ -169,6 +169,18 @@ def _raise_for_status(status):
     raise exc("read rejected by the engine: %s (the reference raises %s here)" % (abi.READ_STATUS_NAMES[int(status)], exc.__name__))
 
 
+def _store_events(eng, ins_store, ev, read_base):
+    """A batch's insertion events with their allele text (A:736-738) into the store.  The text is gathered on the device, from
+    the copy of the batch that eng.process() left there: on the host the gather was half a second per million
+    events (a run of Nanopore-like reads records eight events a read)."""
+    if ev.size == 0:
+        return
+    rows = ev.copy()
+    rows["read"] = (ev["read"].astype(np.int64) - (read_base & 0xFFFFFFFF)) & 0xFFFFFFFF     # read ids are 32-bit, relative to read_base modulo 2^32
+    length, blob = eng.event_text(rows, 0)
+    ins_store.add_text(ev["ref_pos"], length, blob)
+
+
 def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trimmed_reads_fn=None, variants_fn=None,
                 consensus_fn=None, primer_pos_offset=None, min_length=None, min_quality=None, sliding_window_width=None,
                 min_freq_consensus=None, min_freq_variants=None, min_depth_consensus=None, min_depth_variants=None,
@@ -275,7 +287,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             # this batch's events only: the list is drained batch by batch (read ids are 32-bit and relative to
             # read_base modulo 2^32, which a batch never spans)
             ev = eng.drain_events()
-            ins_store.add(batch, ev, read_base & 0xFFFFFFFF)
+            _store_events(eng, ins_store, ev, read_base)
         read_base += batch.n
         del pending[:]
 
@@ -328,7 +340,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                     _raise_for_status(res.status[bad[0]])
                 if do_count:
                     ev = eng.drain_events()
-                    ins_store.add(batch, ev, read_base & 0xFFFFFFFF)
+                    _store_events(eng, ins_store, ev, read_base)
                 read_base += batch.n
         finally:
             if wq is not None:

@@ -70,6 +70,7 @@ struct amp_ctx {
     bool have_ref = false;
     // staging for the host-pointer path
     DBuf s_pos, s_flag, s_tlen, s_lseq, s_cigoff, s_cig, s_seqoff, s_seq, s_qual;
+    int64_t staged_n = -1, staged_ncig = 0, staged_nbases = 0;     // the batch of the last amp_process_batch, still in the buffers above
     DBuf o_pos, o_ncig, o_cig, o_reflen, o_flags, o_status;
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
@@ -1190,6 +1191,7 @@ int amp_process_batch(amp_ctx *c, const amp_reads *r, uint64_t read_base, const 
                      c->s_qual.as<uint8_t>(), (int64_t)n_cig, (int64_t)n_bases};
     amp_trim_out dout{c->o_pos.as<int32_t>(), c->o_ncig.as<uint32_t>(), c->o_cig.as<uint32_t>(), c->o_reflen.as<int32_t>(),
                       c->o_flags.as<uint8_t>(), c->o_status.as<uint8_t>()};
+    c->staged_n = n; c->staged_ncig = (int64_t)n_cig; c->staged_nbases = (int64_t)n_bases;
     int rc = launch_reads(c, &rd, read_base, &dout);
     if (rc != AMP_OK) return rc;
     if (out) {
@@ -1542,8 +1544,16 @@ int amp_coordinate_helpers(amp_ctx *c, int64_t n, const uint32_t *cig_off, const
 
 int amp_event_strings(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base, int64_t n_ev, const amp_ins_event *ev,
                       const uint64_t *off, uint8_t *text) {
-    if (!c || !rd || n_ev < 0 || (n_ev && (!ev || !off || !text))) return AMP_EINVAL;
+    if (!c || n_ev < 0 || (n_ev && (!ev || !off || !text))) return AMP_EINVAL;
     if (n_ev == 0) return AMP_OK;
+    amp_dev_reads staged;
+    if (!rd) {           // the batch of the last amp_process_batch call: its device copy is still in the ctx's staging buffers
+        if (c->staged_n < 0) return AMP_ESTATE;
+        staged = amp_dev_reads{c->staged_n, c->s_pos.as<int32_t>(), c->s_flag.as<uint16_t>(), c->s_tlen.as<int32_t>(), c->s_lseq.as<uint32_t>(),
+                               c->s_cigoff.as<uint32_t>(), c->s_cig.as<uint32_t>(), c->s_seqoff.as<uint32_t>(), c->s_seq.as<uint8_t>(),
+                               c->s_qual.as<uint8_t>(), c->staged_ncig, c->staged_nbases};
+        rd = &staged;
+    }
     for (int64_t e = 0; e < n_ev; ++e) {
         uint64_t i = (uint64_t)ev[e].read - read_base;
         if (i >= (uint64_t)rd->n_reads || ev[e].q_from < 0 || ev[e].q_to < ev[e].q_from ||

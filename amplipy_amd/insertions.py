@@ -54,6 +54,11 @@ class EventStore:
         nib = (batch.seq[b >> 1] >> ((1 - (b & 1)) * 4).astype(np.uint8)) & 15
         self._pos.append(events["ref_pos"].astype(np.int64)); self._len.append(length); self._blob.append(_NT16[nib])
 
+    def add_text(self, ref_pos, length, blob):
+        """The same from allele text gathered elsewhere (Engine.event_text: on the device, from the batch it just processed)."""
+        if len(ref_pos):
+            self._pos.append(np.asarray(ref_pos, np.int64)); self._len.append(np.asarray(length, np.int64)); self._blob.append(np.asarray(blob, np.uint8))
+
     def __len__(self):
         return int(sum(p.size for p in self._pos))
 

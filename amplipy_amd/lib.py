@@ -258,6 +258,20 @@ class Engine:
         cons, vars_, rel = st[2]
         return cons, vars_[:v.n_vars], rel[:v.n_relevant]
 
+    def event_text(self, events, read_base=0, dev_reads=None):
+        """(lengths int64[n], text uint8[sum]) of ``events``: the allele bytes back to back, no Python step per event.
+        dev_reads None = the batch of the last process() call (still staged on the device)."""
+        n = events.size
+        lens = np.maximum(events["q_to"].astype(np.int64) - events["q_from"].astype(np.int64), 0)
+        off = np.zeros(n + 1, np.uint64)
+        np.cumsum(lens, out=off[1:])
+        text = np.zeros(max(int(off[n]), 1), np.uint8)
+        ev = np.ascontiguousarray(events)
+        self._chk(self.L.amp_event_strings(self.h, C.byref(dev_reads) if dev_reads is not None else None, C.c_uint64(read_base), C.c_int64(n),
+                                           C.c_void_p(abi.ptr(ev)), C.c_void_p(abi.ptr(off)), C.c_void_p(abi.ptr(text))),
+                  "amp_event_strings")
+        return lens, text[:int(off[n])]
+
     def event_strings_device(self, dev_reads, events, read_base=0):
         """Strings of ``events`` (INS_EVENT_DTYPE) taken from a device-resident batch."""
         n = events.size

@@ -306,7 +306,10 @@ int amp_call_compact_view(amp_ctx *ctx, const amp_call_params *params, amp_call_
  * caller with several contexts in flight keep the calling kernels of one step in front of the next step's reads. */
 int amp_call_compact_begin(amp_ctx *ctx, const amp_call_params *params);
 /* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
- * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host. */
+ * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host.
+ * reads == NULL: the batch of the last amp_process_batch call (its device copy stays in the ctx until the next one;
+ * AMP_ESTATE when there was none) -- a caller that feeds host batches gets the allele text of a batch's events
+ * without gathering the bases on the host (AmpliPy.py:736-738 builds each string from the read it is looking at). */
 int amp_event_strings(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int64_t n_events,
                       const amp_ins_event *events, const uint64_t *off, uint8_t *text);
 

@@ -579,6 +579,28 @@ def test_many_op_reads_of_every_shape(runner, seed, mq, w):
         assert_same(oracle.process(b, G, mn, mx, mpl, mq, w, do_count=False), runner.process(b, G, mn, mx, mpl, mq, w, do_count=False), b, check_counts=False)
 
 
+def test_event_text_from_the_staged_batch(scheme):
+    """amp_event_strings with reads == NULL (the batch the last amp_process_batch left on the device) gives the allele text
+    the host-side gather gives (A:736-738), and fails cleanly before any batch."""
+    from amplipy_amd import abi, lib
+    from amplipy_amd.insertions import EventStore
+    g, pr, amps, mn, mx, mpl = scheme
+    segs = sorted(synth.make_mixed_segments(g, amps, 4000, seed=77), key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    e = lib.Engine(int(g.size)); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
+    with pytest.raises(Exception):
+        e.event_text(np.zeros(1, abi.INS_EVENT_DTYPE), 0)
+    e.process(b, read_base=1000)
+    ev = e.drain_events()
+    assert ev.size > 100
+    rows = ev.copy(); rows["read"] = ev["read"] - 1000
+    length, blob = e.event_text(rows, 0)
+    a, d = EventStore(), EventStore()
+    a.add(b, ev, 1000); d.add_text(ev["ref_pos"], length, blob)
+    assert a.pairs() == d.pairs()
+    e.close()
+
+
 def test_single_rank_rccl_paths(tmp_path, scheme, monkeypatch):
     """The N > 1 code has to have run before an 8-GPU node shows up: (a) amp_reduce with no communicator is a no-op,
     (b) one-rank RCCL all-reduce of the bound device table through torch.distributed (backend nccl) leaves the
