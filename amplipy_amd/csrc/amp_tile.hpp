@@ -63,6 +63,18 @@ constexpr uint32_t DEFER_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t GL_STATUS_ONLY = 0x80000000u;   // counted by the fast kernel; a base could not be counted: exact status wanted
 constexpr uint32_t GL_LONG = 0x40000000u;          // tens of CIGAR ops: taken by k_long (amp_wave.hpp), not a row of this pass
 constexpr uint32_t GL_INDEX_MASK = 0x3FFFFFFFu;
+// Where k_tile<LIST> finds its list when k_gcompact has not packed it (the common case: one launch less per batch).  The fast
+// kernel leaves one list segment per block (entries [b * rpb, b * rpb + gcnt[b]) of glist); a block of the tile kernel sums
+// the counts itself (a KB from L2), derives the geometry k_gcompact would have written, and finds entry li of the virtual
+// dense list by a binary search over the prefix sums.
+constexpr int GL_MAXSEG = 256;
+struct ListSrc {
+    const uint32_t *glist, *gcnt;   // null: the list is dense (rlist)
+    int n_gseg, rpb;
+    uint32_t gen_grid;
+    uint32_t *segfirst;             // [gen_grid] out: read index of the first entry of every block's range (the heavy pass anchors its window there)
+    struct GenGeo *geo_out;         // out (block 0): the geometry, for the heavy pass
+};
 struct GenGeo {            // geometry of the general pass, decided on the device by k_gcompact
     uint32_t n_list;       // entries of the dense list
     uint32_t tpb;          // tiles per block of k_tile<LIST>
@@ -85,6 +97,7 @@ struct BlockLds {
     uint32_t lut[16];                 // BAM base code -> byte offset of its count plane
     uint32_t dcount;                  // light entries (indels only) of this block's deferred-list segment, from its front
     uint32_t dcount2;                 // heavy entries (whole read / exact status), from its back
+    uint32_t gpre[GL_MAXSEG + 1];     // LIST without k_gcompact: entries in front of every list segment
     WaveLds wv[T_WAVES];
 };
 
@@ -559,23 +572,54 @@ template <bool STAMPS, bool SPLIT, bool LIST>
 __global__ void __launch_bounds__(T_WAVES * 64, 4)
 k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *dlist,
        uint32_t *dcnt, int tiles_per_block, SplitDesc sd, const uint32_t *rlist, const GenGeo *geo,
-       uint32_t dcnt_stride AMP_PHASES_PARAM) {
+       uint32_t dcnt_stride, ListSrc ls AMP_PHASES_PARAM) {
 #ifndef AMP_DEV
     constexpr uint32_t phases = 0xFFu;     // the shipped library cannot mask phases off
 #endif
     __shared__ BlockLds L;
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (LIST) tiles_per_block = (int)geo->tpb;
-    const int64_t n = LIST ? (int64_t)geo->n_list : rd.n_reads;
+    const bool direct = LIST && ls.glist != nullptr;
+    uint32_t n_list_direct = 0;
+    if (direct) {
+        if (tid <= GL_MAXSEG) L.gpre[tid] = tid < ls.n_gseg ? ls.gcnt[tid] : 0u;
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t a0 = L.gpre[4 * lane], a1 = L.gpre[4 * lane + 1], a2 = L.gpre[4 * lane + 2], a3 = L.gpre[4 * lane + 3];
+            uint32_t total;
+            const uint32_t ex = wave_excl_scan(a0 + a1 + a2 + a3, lane, total);
+            L.gpre[4 * lane] = ex; L.gpre[4 * lane + 1] = ex + a0; L.gpre[4 * lane + 2] = ex + a0 + a1; L.gpre[4 * lane + 3] = ex + a0 + a1 + a2;
+            if (lane == 0) L.gpre[GL_MAXSEG] = total;
+        }
+        __syncthreads();
+        n_list_direct = L.gpre[GL_MAXSEG];
+        const uint32_t tiles = (n_list_direct + TILE - 1) / TILE;
+        uint32_t tpb = (tiles + ls.gen_grid - 1) / ls.gen_grid;
+        tpb = ((tpb + T_WAVES - 1) / T_WAVES) * T_WAVES;
+        if (tpb < (uint32_t)T_WAVES) tpb = T_WAVES;
+        tiles_per_block = (int)tpb;
+        if (blockIdx.x == 0 && tid == 0) {
+            ls.geo_out->n_list = n_list_direct; ls.geo_out->tpb = tpb; ls.geo_out->n_seg = (tiles + tpb - 1) / tpb; ls.geo_out->live_counted = 0u;
+            ctr[7] = n_list_direct;                   // (amp_debug_counters: reads of the last batch that took the general pass)
+        }
+    } else if (LIST) tiles_per_block = (int)geo->tpb;
+    const int64_t n = direct ? (int64_t)n_list_direct : LIST ? (int64_t)geo->n_list : rd.n_reads;
+    // entry li of the list
+    const auto list_entry = [&](int64_t li) -> uint32_t {
+        if (!direct) return rlist[li];
+        int lo = 0, hi = ls.n_gseg - 1;               // the last segment that starts at or in front of li
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)L.gpre[mid] <= li) lo = mid; else hi = mid - 1; }
+        return ls.glist[(size_t)lo * (size_t)ls.rpb + (size_t)(li - (int64_t)L.gpre[lo])];
+    };
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const int64_t tile_begin = (int64_t)blockIdx.x * tiles_per_block;
     const int64_t tile_end = tile_begin + tiles_per_block < n_tiles ? tile_begin + tiles_per_block : n_tiles;
-    if (tile_begin >= tile_end || (LIST && geo->live_counted && ctr[28] == 0ull)) {
+    if (tile_begin >= tile_end || (LIST && !direct && geo->live_counted && ctr[28] == 0ull)) {
         if (threadIdx.x == 0) { dcnt[blockIdx.x] = 0; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = 0; }
         return;
     }
 
+    if (LIST && ls.segfirst && tid == 0) ls.segfirst[blockIdx.x] = list_entry(tile_begin * TILE) & GL_INDEX_MASK;
     lds_u32 *const win = (lds_u32 *)L.win;
     lds_u32 *const lut = (lds_u32 *)L.lut;
     for (int i = tid; i < AMP_NSYM * T_W; i += T_WAVES * 64) win[i] = 0;
@@ -599,7 +643,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 
     for (int64_t t0 = tile_begin; t0 < tile_end; t0 += T_WAVES) {
         // ---- window management (uniform over the block) ------------------------------------
-        const int32_t first_pos = rd.pos[LIST ? (int64_t)(rlist[t0 * TILE] & GL_INDEX_MASK) : t0 * TILE];
+        const int32_t first_pos = rd.pos[LIST ? (int64_t)(list_entry(t0 * TILE) & GL_INDEX_MASK) : t0 * TILE];
         if (win_base == NO_WINDOW || first_pos < win_base || first_pos - win_base >= T_W / 2) {
             __syncthreads();
             if (win_base != NO_WINDOW) {
@@ -631,7 +675,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         const int64_t li = tile * TILE + lane;           // row of the batch, or of the list
         bool valid = li < n;
         uint32_t lent = 0;
-        if (LIST && valid) { lent = rlist[li]; if (lent & GL_LONG) valid = false; }
+        if (LIST && valid) { lent = list_entry(li); if (lent & GL_LONG) valid = false; }
         if (LIST && !__ballot(valid)) continue;            // a tile of reads that k_long took
         const int64_t i = LIST ? (int64_t)(lent & GL_INDEX_MASK) : li;
         const bool status_wanted = LIST && (lent & GL_STATUS_ONLY);      // the fast kernel counted it: exact status only
@@ -979,10 +1023,10 @@ static inline int tile_launch(const KParams &P, const amp_dev_reads &rd, uint64_
     const TileGrid tg = tile_grid(rd.n_reads, n_cu);
     const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
 #ifdef AMP_DEV
-    if (phases & 0x100u) k_tile<true, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
+    if (phases & 0x100u) k_tile<true, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid, ListSrc{} AMP_PHASES_ARG(phases));
     else
 #endif
-    k_tile<false, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
+    k_tile<false, false, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, none, nullptr, nullptr, (uint32_t)tg.grid, ListSrc{} AMP_PHASES_ARG(phases));
     return (int)hipGetLastError();
 }
 
@@ -1085,7 +1129,7 @@ static inline int split_launch(const KParams &P, const amp_dev_reads &rd, uint64
     const unsigned g1 = (unsigned)((rd.n_reads + S_WAVES * 64 - 1) / (S_WAVES * 64));
     k_trim<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, out, sd);
     if (P.do_trim && P.window <= 8 && (phases & 2u)) k_scan<<<g1, S_WAVES * 64, 0, stream>>>(P, rd, sd, phases);
-    k_tile<false, true, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, sd, nullptr, nullptr, (uint32_t)tg.grid AMP_PHASES_ARG(phases));
+    k_tile<false, true, false><<<(unsigned)tg.grid, T_WAVES * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, dlist, dcnt, (int)tg.tpb, sd, nullptr, nullptr, (uint32_t)tg.grid, ListSrc{} AMP_PHASES_ARG(phases));
     return (int)hipGetLastError();
 }
 

@@ -479,7 +479,7 @@ template <bool SPARSE>
 __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out,
                                            uint32_t *scratch, uint32_t *counts, const EventBuf &eb, const uint32_t *dlist,
                                            const uint32_t *dcnt, long long tiles_per_block, long long n_seg, long long dcnt_stride,
-                                           const uint32_t *rlist) {
+                                           const uint32_t *segfirst) {
     uint32_t *const s_cig = L.cig, *const s_win = L.win, *const s_coop = L.coop, *const s_ev = L.ev, *const s_ucnt = L.ucnt;
     uint32_t &s_ncoop = L.ncoop, &s_nev = L.nev;
     unsigned long long &s_evbase = L.evbase, &s_mask = L.mask;
@@ -522,7 +522,7 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
     for (uint32_t k = threadIdx.x; k < D_PLANES * D_WIN; k += blockDim.x) s_win[k] = 0;
     // sorted input: no read of this pass starts left of the first read of its first tile range
     const int64_t first_row = sb_first * tiles_per_block * TILE;
-    int32_t base = rd.pos[rlist ? (int64_t)(rlist[first_row] & GL_INDEX_MASK) : first_row];
+    int32_t base = rd.pos[segfirst ? (int64_t)segfirst[sb_first] : first_row];
     if (base < 0) base = 0;
     __syncthreads();
     const uint32_t cnt = s_ucnt[D_UNIT];
@@ -665,13 +665,13 @@ __device__ __forceinline__ void heavy_pass(HeavyLds &L, const KParams &P, const 
 __global__ void __launch_bounds__(256)
 k_deferred_heavy(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *scratch, uint32_t *counts,
                  EventBuf eb, const uint32_t *dlist, const uint32_t *dcnt, long long tiles_per_block, long long n_seg,
-                 const GenGeo *geo, long long dcnt_stride, const uint32_t *rlist) {
+                 const GenGeo *geo, long long dcnt_stride, const uint32_t *segfirst) {
     __shared__ HeavyLds L;
     if (__hip_atomic_load(&eb.ctr[24], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;   // set by the tile kernel
     if (geo) { tiles_per_block = (long long)geo->tpb; n_seg = (long long)geo->n_seg; }
-    heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
+    heavy_pass<true>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, segfirst);
     __syncthreads();
-    heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, rlist);
+    heavy_pass<false>(L, P, rd, read_base, out, scratch, counts, eb, dlist, dcnt, tiles_per_block, n_seg, dcnt_stride, segfirst);
 }
 
 // amp_reset: zeroes the device table and the counters
@@ -1074,7 +1074,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // a batch of reads with many CIGAR ops (eight a read on average: Nanopore-like) gets k_long (amp_wave.hpp) for them; the
     // results do not depend on this choice
     const bool long_kernel = variant == 4 && rd->n_cig >= 8 * n;
-    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + (long_kernel ? 2 * (size_t)n : 0) : 0;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + 1024 + (long_kernel ? 2 * (size_t)n : 0) : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
@@ -1108,11 +1108,17 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-        uint32_t *llist = (uint32_t *)geo + 4, *lpos = llist + n;
+        uint32_t *segfirst = (uint32_t *)geo + 4, *llist = segfirst + 1024, *lpos = llist + n;
+        // the list stays in the fast kernel's per-block segments and the tile kernel indexes them itself -- one launch less --
+        // unless k_long needs the dense list (to flag its reads in) or the fast kernel ran more blocks than the tile kernel's table holds
+        const bool direct = !long_kernel && fg.grid <= GL_MAXSEG && gen_grid <= 1024;
+        const ListSrc ls{direct ? glist : nullptr, direct ? gcnt : nullptr, (int)fg.grid, (int)fg.rpb, (uint32_t)gen_grid, segfirst, geo};
         // (ctr[26..28] -- k_long's list length, its chunk ticket, the entries left to the tile kernel -- are zeroed by the fast kernel)
-        k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr,
-                                                              rd->cig_off32, llist, lpos, long_kernel ? L_MAXOPS - 4 : 0);
-        HIPCHK(c, hipGetLastError());
+        if (!direct) {
+            k_gcompact<<<(unsigned)fg.grid, 256, 0, c->stream>>>(glist, gcnt, (int)fg.rpb, n, gdense, geo, (uint32_t)gen_grid, c->d_ctr,
+                                                                  rd->cig_off32, llist, lpos, long_kernel ? L_MAXOPS - 4 : 0);
+            HIPCHK(c, hipGetLastError());
+        }
         if (long_kernel) {
             k_long<<<2u * (unsigned)c->n_cu, L_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, llist, lpos, gdense);
             HIPCHK(c, hipGetLastError());
@@ -1121,16 +1127,16 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         if (c->phases & 0x100u) {           // stamps of the general pass alone: the fast kernel's are dropped
             HIPCHK(c, hipMemsetAsync(&c->d_ctr[4], 0, 12 * sizeof(unsigned long long), c->stream));
             k_tile<true, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
-                                                                                       gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
+                                                                                       direct ? nullptr : gdense, geo, (uint32_t)tg.grid, ls AMP_PHASES_ARG(c->phases));
         } else
 #endif
         k_tile<false, false, true><<<(unsigned)gen_grid, T_WAVES * 64, 0, c->stream>>>(P, *rd, read_base, out, c->d_counts, eb, dlist, dcnt, 0, none,
-                                                                                    gdense, geo, (uint32_t)tg.grid AMP_PHASES_ARG(c->phases));
+                                                                                    direct ? nullptr : gdense, geo, (uint32_t)tg.grid, ls AMP_PHASES_ARG(c->phases));
         HIPCHK(c, hipGetLastError());
         // (the tile kernel does the indels of regular reads itself and raises the heavy pass's flag: k_deferred_light, round 1's
         // second-pass kernel for them, is no longer launched)
         k_deferred_heavy<<<(unsigned)std::min<int64_t>(tg.grid, 2 * (int64_t)c->n_cu), 256, 0, c->stream>>>(
-            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo, (long long)tg.grid, gdense);
+            P, *rd, read_base, out, scr, c->d_counts, eb, dlist, dcnt, 0, 0, geo, (long long)tg.grid, segfirst);
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -25,8 +25,8 @@ Either way the counts are stitched with one all-reduce of the 7 x 29,903 uint32 
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
   roofline:     algorithmic bytes of the CIGAR-scan pass / its HIP-event duration vs 8 TB/s.  The
-                scan pass is what amp_process_batch_device launches: k_fast (simple reads), k_gcompact,
-                k_tile<LIST> (the other reads), k_deferred_heavy
+                scan pass is what amp_process_batch_device launches: k_fast (simple reads), k_tile<LIST>
+                (the other reads, straight from the fast kernel's per-block lists), k_deferred_heavy
   cpu_baseline: the C restatement in oracle/ timed on this host's cores on the same batch, plus the
                 pure-Python restatement on a 100 k-read subsample
   e2e:          file-to-file rates outside the timed region (host pointers, BAM -> calls, BAM -> BAM)
@@ -44,7 +44,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-SCAN_KERNELS = {4: "scan pass: k_fast + k_gcompact + k_tile<LIST> + k_deferred_heavy",
+SCAN_KERNELS = {4: "scan pass: k_fast + k_tile<LIST> + k_deferred_heavy",
                 2: "scan pass: k_tile + k_deferred_heavy",
                 3: "scan pass: k_trim + k_scan + k_tile<SPLIT> + k_deferred_heavy", 1: "k_reads_lane"}
 
