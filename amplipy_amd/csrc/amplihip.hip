@@ -75,12 +75,9 @@ struct amp_ctx {
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
     void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
-    int64_t last_nv = 0, last_nr = 0, guess_v = 0, guess_r = 0;
-    bool copy_busy = false;        // a copy of the calling image may still be in flight on copy_stream (ev_call says when it is done)
     bool call_pending = false;     // amp_call_compact_begin has enqueued the calling kernels; amp_call_compact_view picks them up
     amp_call_params call_pending_params{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr, ev_img = nullptr;
-    hipStream_t copy_stream = nullptr;    // the calling image travels to the host beside the work stream, not in it
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr;
     bool timed = false;
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
@@ -922,9 +919,7 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipMemsetAsync(c->d_ctr, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess) return fail(AMP_EHIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_img, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(AMP_EHIP);
+        hipEventCreateWithFlags(&c->ev_call, hipEventDisableTiming) != hipSuccess) return fail(AMP_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
 #ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
@@ -955,8 +950,6 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->ev_call) (void)hipEventDestroy(c->ev_call);
-    if (c->ev_img) (void)hipEventDestroy(c->ev_img);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1402,14 +1395,15 @@ struct CallImage {
     }
 };
 
-// Enqueues the calling kernels and the copy of the image's likely-used prefix on the ctx stream; does not wait.
+// Enqueues the calling kernels on the ctx stream; does not wait.  (The caller has read the image of the ctx's previous call:
+// the views are valid until the next call_* on the ctx.)
 static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
     const int32_t G = c->ref_len;
-    // device buffer: [per-position calls][block counts] | output image [totals 64 B][consensus][records][relevant positions]
-    // The output image has the same layout in the pinned host buffer, so its used prefix travels in ONE copy.
+    // device buffer: [per-position calls][block counts]; pinned host buffer: the output image [totals 64 B][consensus][records]
+    // [relevant positions]
     const CallImage L(G);
-    HIPCHK(c, c->call_buf.ensure(L.off_img + L.img_size + 64));
-    uint8_t *base = c->call_buf.as<uint8_t>(), *img = base + L.off_img;
+    HIPCHK(c, c->call_buf.ensure(L.off_img + 64));
+    uint8_t *base = c->call_buf.as<uint8_t>();
     amp_pos_call *d_pc = (amp_pos_call *)base;
     if (c->h_pin_cap < L.img_size) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1417,25 +1411,17 @@ static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
         HIPCHK(c, hipHostMalloc(&c->h_pin, L.img_size, hipHostMallocDefault));
         c->h_pin_cap = L.img_size;
     }
-    // (the image of this ctx's previous call must have left the device before it is overwritten)
-    if (c->copy_busy) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_call, 0));
+    // The result image is written by the compaction kernel straight into the pinned host buffer (plain stores over the
+    // host link; half a megabyte): no copy to place.  A copy on a stream of its own was only served once the kernels
+    // queued behind the calls had drained (0.61 ms per step with three steps in flight instead of 0.31), a copy in the
+    // work stream cost a launch gap more (0.308 -> 0.294 ms per bench step with this).
+    uint8_t *hz = (uint8_t *)c->h_pin;
     k_call<<<L.nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + L.off_blk));
     HIPCHK(c, hipGetLastError());
-    k_call_compact<<<L.nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + L.off_blk), (int8_t *)(img + L.img_cons),
-                                                  (amp_var_rec *)(img + L.img_vars), (int32_t *)(img + L.img_rel), (unsigned long long *)img);
+    k_call_compact<<<L.nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + L.off_blk), (int8_t *)(hz + L.img_cons),
+                                                  (amp_var_rec *)(hz + L.img_vars), (int32_t *)(hz + L.img_rel), (unsigned long long *)hz);
     HIPCHK(c, hipGetLastError());
-    uint8_t *hp = (uint8_t *)c->h_pin;
-    // as many records as the previous call produced (plus a margin); more copies only when this call produced more
-    c->guess_v = std::min<int64_t>(G, c->last_nv + c->last_nv / 4 + 256);
-    c->guess_r = c->last_nr ? std::min<int64_t>(G, c->last_nr + c->last_nr / 4 + 64) : 0;
-    // The copy runs on its own stream behind the kernels: in the work stream it would hold up whatever the caller enqueues
-    // next (the following batch) for the ~20 us half a megabyte takes over PCIe.
-    HIPCHK(c, hipEventRecord(c->ev_img, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_img, 0));
-    HIPCHK(c, hipMemcpyAsync(hp, img, L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->copy_stream));
-    if (c->guess_r) HIPCHK(c, hipMemcpyAsync(hp + L.img_rel, img + L.img_rel, (size_t)c->guess_r * 4, hipMemcpyDeviceToHost, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->ev_call, c->copy_stream));     // "the image has arrived"
-    c->copy_busy = true;
+    HIPCHK(c, hipEventRecord(c->ev_call, c->stream));     // "the image has arrived"
     return AMP_OK;
 }
 
@@ -1459,23 +1445,13 @@ int amp_call_compact_view(amp_ctx *c, const amp_call_params *pr, amp_call_view *
     const bool begun = c->call_pending && memcmp(&c->call_pending_params, pr, sizeof(*pr)) == 0;
     c->call_pending = false;
     if (!begun) { const int rc = call_compact_enqueue(c, pr); if (rc != AMP_OK) return rc; }
-    uint8_t *img = c->call_buf.as<uint8_t>() + L.off_img;
     uint8_t *hp = (uint8_t *)c->h_pin;
     const unsigned long long *h_nn = (const unsigned long long *)hp;
     const int8_t *h_cons = (const int8_t *)(hp + L.img_cons);
     amp_var_rec *h_vars = (amp_var_rec *)(hp + L.img_vars);
     int32_t *h_rel = (int32_t *)(hp + L.img_rel);
     HIPCHK(c, hipEventSynchronize(c->ev_call));
-    c->copy_busy = false;
     const int64_t nv = (int64_t)h_nn[0], nr = (int64_t)h_nn[1];
-    c->last_nv = nv; c->last_nr = nr;
-    if (nv > c->guess_v || nr > c->guess_r) {
-        if (nv > c->guess_v) HIPCHK(c, hipMemcpyAsync(h_vars + c->guess_v, img + L.img_vars + (size_t)c->guess_v * sizeof(amp_var_rec),
-                                                      (size_t)(nv - c->guess_v) * sizeof(amp_var_rec), hipMemcpyDeviceToHost, c->stream));
-        if (nr > c->guess_r) HIPCHK(c, hipMemcpyAsync(h_rel + c->guess_r, img + L.img_rel + (size_t)c->guess_r * 4, (size_t)(nr - c->guess_r) * 4,
-                                                      hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
     *view = amp_call_view{h_cons, h_vars, h_rel, nv, nr};
     return AMP_OK;
 }
