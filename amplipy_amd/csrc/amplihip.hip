@@ -1153,6 +1153,7 @@ int amp_process_batch_device(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_
     if (rd->n_reads && (!rd->pos || !rd->flag || !rd->tlen || !rd->lseq || !rd->cig_off32 || !rd->cig || !rd->seq_off8 ||
                         !rd->seq || !rd->qual)) return AMP_EINVAL;
     Guard g(c);
+    c->staged_n = -1;          // (amp_event_strings(reads = NULL) refers to the last HOST batch: there is none now)
     return launch_reads(c, rd, read_base, dev_out);
 }
 
