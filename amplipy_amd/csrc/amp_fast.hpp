@@ -915,20 +915,27 @@ k_gcompact(const uint32_t *__restrict__ glist, const uint32_t *__restrict__ gcnt
     if (long_max_ops) {
         // the reads with more ops than the tile kernel's columns hold (it would only pass them on) and no more than k_long's rows:
         // flagged in the dense list and listed, in order, for k_long (one reservation per block)
-        const auto is_long = [&](uint32_t k) -> bool {
-            if (k >= cnt) return false;
+        // 1 = more ops than the tile kernel's columns hold, 2 = any read k_long can take.  A segment that is mostly made of
+        // the first kind (a Nanopore-like batch) hands over every read it can: the few others would leave the tile kernel
+        // one or two lanes of work per 64-read tile (79 us on 200,000 such reads)
+        const auto kind = [&](uint32_t k) -> uint32_t {
+            if (k >= cnt) return 0u;
             const uint32_t e = src[k];
-            if (e & GL_STATUS_ONLY) return false;
+            if (e & GL_STATUS_ONLY) return 0u;
             const uint32_t i = e & GL_INDEX_MASK, nops = cig_off32[i + 1] - cig_off32[i];
-            return (int)nops + 3 > T_MAXOPS && (int)nops <= long_max_ops;
+            if ((int)nops > long_max_ops) return 0u;
+            return (int)nops + 3 > T_MAXOPS ? 1u : 2u;
         };
-        uint32_t mine = 0;
-        for (uint32_t k = tid; k < cnt; k += 256) mine += is_long(k) ? 1u : 0u;
-        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+        uint32_t strict = 0, elig = 0;
+        for (uint32_t k = tid; k < cnt; k += 256) { const uint32_t kd = kind(k); strict += kd == 1u ? 1u : 0u; elig += kd ? 1u : 0u; }
+        for (int o = 32; o > 0; o >>= 1) { strict += __shfl_down(strict, o); elig += __shfl_down(elig, o); }
         __syncthreads();
-        if ((tid & 63) == 0) s_lw[tid >> 6] = mine;
+        if ((tid & 63) == 0) { s_lw[tid >> 6] = strict; s_part[tid >> 6] = elig; }      // (s_part: the offsets it held are in `off`)
         __syncthreads();
-        const uint32_t total = s_lw[0] + s_lw[1] + s_lw[2] + s_lw[3];
+        const uint32_t n_strict = s_lw[0] + s_lw[1] + s_lw[2] + s_lw[3], n_elig = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const bool promote = (unsigned long long)n_strict * 4ull >= (unsigned long long)cnt * 3ull;
+        const uint32_t total = promote ? n_elig : n_strict;
+        const auto is_long = [&](uint32_t k) -> bool { const uint32_t kd = kind(k); return kd == 1u || (promote && kd == 2u); };
         if (tid == 0 && cnt > total) atomicAdd(&ctr[28], (unsigned long long)(cnt - total));      // entries left to the tile kernel
         if (total) {                                   // (uniform over the block)
             if (tid == 0) s_lbase = (uint32_t)atomicAdd(&ctr[26], (unsigned long long)total);
