@@ -86,19 +86,24 @@ def alleles_from_counts(symbol_counts):
     return total, sorted(((c, c / total, k) for k, c in symbol_counts.items() if c != 0), reverse=True)
 
 
-def _helpers(cigar, ref_start, ref_pos=0, query_pos=0):
+def _helpers(cigar, ref_start, ref_pos=0, query_pos=0, which=None):
+    """One device call for the three helpers; only the status of the helper that was asked for is raised (the reference's
+    get_pos_on_query returns at the op that holds ref_pos without looking at later ones, and fix_cigar consults no table)."""
     e = _engine(1)
     oq, orf, fixed, st = e.coordinate_helpers([[(int(op), int(l)) for op, l in cigar]], [ref_start], [ref_pos], [query_pos])
-    _raise(st[0])
+    if which == "query":
+        _raise(int(st[0]) & 15)
+    elif which == "ref":
+        _raise(int(st[0]) >> 4)
     return int(oq[0]), int(orf[0]), fixed[0]
 
 
 def get_pos_on_query(cigar, ref_pos, ref_start):
-    return _helpers(cigar, ref_start, ref_pos=ref_pos)[0]
+    return _helpers(cigar, ref_start, ref_pos=ref_pos, which="query")[0]
 
 
 def get_pos_on_ref(cigar, query_pos, ref_start):
-    return _helpers(cigar, ref_start, query_pos=query_pos)[1]
+    return _helpers(cigar, ref_start, query_pos=query_pos, which="ref")[1]
 
 
 def fix_cigar(cigar):

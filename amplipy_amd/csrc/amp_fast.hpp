@@ -37,7 +37,13 @@
 
 namespace amp {
 
-constexpr int F_WAVES = 8;            // waves per block (one block per CU: LDS)
+#ifndef AMP_F_WAVES
+#define AMP_F_WAVES 8
+#endif
+#ifndef AMP_F_LDSPAD
+#define AMP_F_LDSPAD 0
+#endif
+constexpr int F_WAVES = AMP_F_WAVES;  // waves per block (one block per CU: LDS)
 constexpr int F_NP = 10;              // 16-base pieces per read held in registers
 constexpr int F_MAXLEN = 152;         // longest read the fast path takes: F_NP pieces must cover it from 8 bases before its start
 constexpr int F_PW = 256;             // reference positions covered by a wave's packed window
@@ -261,6 +267,10 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     __shared__ uint32_t s_pwin[F_WAVES][F_REP * F_REPW];              // per wave: packed counters, byte c of a word = base c (A C G T)
     __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
     __shared__ uint32_t s_ticket, s_gcur;                             // next tile of the block to hand out; entries of its general list
+#if AMP_F_LDSPAD > 0
+    __shared__ uint32_t s_pad[AMP_F_LDSPAD / 4];                      // (occupancy experiments: keeps a second block off the CU)
+    if (P.ref_len == -12345) s_pad[threadIdx.x] = 1;
+#endif
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     F_STAMP_DECL;
@@ -311,6 +321,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 
     // folds the wave's packed window into the block's 32-bit window (or the global table) and clears it
     auto fold = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm adds of the counting phase are invisible to the compiler's wait counts
         wave_sync();
 #pragma unroll 1
         for (int idx = lane; idx < F_PW; idx += 64) {
@@ -873,6 +884,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     F_EPI(1);
     if (pw_tiles && n_tb) fold();
     F_EPI(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (asm adds into the block's window: deletions, insertion tally, careful loop)
     __syncthreads();
 #if defined(AMP_DEV) && defined(AMP_ABL)
     if (AMP_ABL & 16) return;

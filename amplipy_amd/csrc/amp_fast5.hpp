@@ -1,0 +1,685 @@
+// amp_fast5.hpp -- the fast kernel, second generation (variant 5, the default): trim + pileup of the reads whose CIGAR has
+// the shape [S a][M m1]([I|D k][M m2])[S c], one lane per read, every byte of the batch loaded once.  CDNA4 / gfx950.
+//
+// Same decomposition as amp_fast.hpp (variant 4: a wave takes a TILE of 64 consecutive reads of the sorted batch, lane =
+// read, closed-form trims from amp_read.hpp, packed per-wave counter windows in LDS) with a leaner instruction stream.
+// What the counters of variant 4 showed (profiles/r03_*): the kernel is bound by instruction issue -- a wave issues one
+// instruction per ~4.4 cycles, a tile cost ~4,300 of them, two waves per SIMD slow each other by a quarter in EVERY
+// phase -- not by HBM, LDS or the I-cache.  So this version spends instructions, not bytes:
+//   * a tile's qualities AND packed bases arrive by LDS-DMA in two staging buffers and are consumed from there, 16 bases
+//     (a PIECE) at a time: no register copy of the read (60 VGPRs in variant 4), no register-staged base bytes, no LDS
+//     write + read-back of the bases
+//   * one pass over the qualities turns every piece into 16 failing-window bits + 16 "quality >= min_quality" bits
+//     (one VGPR per piece); the staging buffer is then free for the next tile's qualities while the bases are counted
+//   * the counted-base test, the range mask and the counter shift of a piece are computed from those bits with byte
+//     tricks that need no per-base work besides the SDWA shift + ds_add pair; codes outside A C G T are found with one
+//     popcount / has-zero-nibble test per piece (pad nibbles of the staged rows are patched to a valid code first)
+//   * every vector-memory operation of the loop that returns data is issued by inline assembly or as a plain load that
+//     is first touched behind the ONE wait at the top of the loop, so the compiler never drains the prefetches early
+//     (its wait-count pass answers a touched in-flight register with vmcnt(0)): the loop has two full drains, both of
+//     loads issued a phase or more before (top: next qualities, primer-table entries, CIGAR words, header;
+//     before counting: this tile's bases)
+//   * results are stored in the tile they belong to (no one-tile deferral, no packed `pending' registers)
+// Reads it does not take (other CIGARs, QUAL '*', more than F5_MAXLEN bases, rows that do not fit the staging buffer)
+// go on the block's list for the general pass, exactly as in variant 4.
+#pragma once
+
+#include "amp_fast.hpp"
+
+namespace amp {
+
+#ifndef AMP_F5_WAVES
+#define AMP_F5_WAVES 8
+#endif
+constexpr int F5_WAVES = AMP_F5_WAVES;    // waves per block, one block per CU
+constexpr int F5_NP = 20;                 // 16-base pieces of the longest read taken
+constexpr int F5_MAXLEN = 304;            // F5_NP pieces cover it from 8 bases before its start
+constexpr int F5_QRUN = 9728;             // quality bytes of a tile's run (64 reads of 152 padded bases)
+constexpr int F5_PAD = 16;                // bytes in front of / behind a staged run
+constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
+constexpr int F5_REP = 4;                 // replicas of a wave's packed window (bank conflicts of two cost nothing: the
+constexpr int F5_REPW = F_PW + 1;         // LDS takes four cycles to receive an atomic's operands)
+
+// bit 7 of every byte: quality >= mq (mq <= 128, mqb = mq in every byte); three instructions
+__device__ __forceinline__ uint32_t ok80(uint32_t q, uint32_t mqb) {
+    const uint32_t t = ((q & 0x7F7F7F7Fu) | 0x80808080u) - mqb;
+    return (t | q) & 0x80808080u;
+}
+// 16 bits "quality >= mq" of a piece
+__device__ __forceinline__ uint32_t ok_bits16(const uint4 &q, uint32_t mqb) {
+    // byte flags 0x80 times the weights 1 2 4 8 (16 32 64 128) add up to the nibble << 7
+    uint32_t lo = __builtin_amdgcn_udot4(ok80(q.x, mqb), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(ok80(q.y, mqb), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(ok80(q.z, mqb), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(ok80(q.w, mqb), 0x80402010u, hi, false);
+    return (lo >> 7) | ((hi >> 7) << 8);
+}
+// zero when all 8 nibbles of x hold exactly one bit (A C G T)
+__device__ __forceinline__ uint32_t nibbles_bad(uint32_t x, uint32_t y) {
+    const uint32_t z = ((x - 0x11111111u) & ~x & 0x88888888u) | ((y - 0x11111111u) & ~y & 0x88888888u);      // a zero nibble
+    return z | ((uint32_t)(__builtin_popcount(x) + __builtin_popcount(y)) ^ 16u);
+}
+// counter word at wb + 4 * B  +=  (byte JV of val) << (byte JS of sh)
+template <int JS, int JV, int B>
+__device__ __forceinline__ void add_base2(uint32_t wb, uint32_t sh, uint32_t val) {
+#define AMP_AB2(js, jv) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #js " src1_sel:BYTE_" #jv "\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory")
+    uint32_t t;
+    if (JS == 0 && JV == 0) AMP_AB2(0, 0); if (JS == 0 && JV == 1) AMP_AB2(0, 1); if (JS == 0 && JV == 2) AMP_AB2(0, 2); if (JS == 0 && JV == 3) AMP_AB2(0, 3);
+    if (JS == 1 && JV == 0) AMP_AB2(1, 0); if (JS == 1 && JV == 1) AMP_AB2(1, 1); if (JS == 1 && JV == 2) AMP_AB2(1, 2); if (JS == 1 && JV == 3) AMP_AB2(1, 3);
+    if (JS == 2 && JV == 0) AMP_AB2(2, 0); if (JS == 2 && JV == 1) AMP_AB2(2, 1); if (JS == 2 && JV == 2) AMP_AB2(2, 2); if (JS == 2 && JV == 3) AMP_AB2(2, 3);
+    if (JS == 3 && JV == 0) AMP_AB2(3, 0); if (JS == 3 && JV == 1) AMP_AB2(3, 1); if (JS == 3 && JV == 2) AMP_AB2(3, 2); if (JS == 3 && JV == 3) AMP_AB2(3, 3);
+#undef AMP_AB2
+}
+// LDS-DMA of 16 bytes per lane, issued where the compiler cannot see it (see the head of the file)
+__device__ __forceinline__ void dma16(const void *g, const lds_u8 *l) {
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)l);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
+}
+
+// One piece (16 bases): packed codes sq, counted-base bits m16 (bit b: base b of the piece is inside the counted range
+// and good enough), window offset d0 of its base 0, against the lane's replica of the wave's packed window.
+// Returns true when the careful loop has to redo the piece (a code outside A C G T in it, or it leaves the window).
+__device__ __forceinline__ bool count_piece5(const uint2 &sq, uint32_t m16, int32_t d0, uint32_t pw_lim, uint32_t wrep) {
+    const bool inwin = pw_lim >= 16u && (uint32_t)d0 <= pw_lim - 16u;
+    const bool redo = m16 != 0u && (!inwin || nibbles_bad(sq.x, sq.y) != 0u);
+    const uint32_t m = redo ? 0u : m16;
+    // shift counts of the even / odd bases of each half (the high nibble of a byte is the even base)
+    const uint32_t se0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.x >> 4) & 0x07070707u);
+    const uint32_t so0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.x & 0x07070707u);
+    const uint32_t se1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.y >> 4) & 0x07070707u);
+    const uint32_t so1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.y & 0x07070707u);
+    const uint32_t f0 = nibble_to_bytes(m, 0), f1 = nibble_to_bytes(m, 1), f2 = nibble_to_bytes(m, 2), f3 = nibble_to_bytes(m, 3);
+    const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u : 0u);
+    add_base2<0, 0, 0>(wb, se0, f0);   add_base2<0, 1, 1>(wb, so0, f0);   add_base2<1, 2, 2>(wb, se0, f0);   add_base2<1, 3, 3>(wb, so0, f0);
+    add_base2<2, 0, 4>(wb, se0, f1);   add_base2<2, 1, 5>(wb, so0, f1);   add_base2<3, 2, 6>(wb, se0, f1);   add_base2<3, 3, 7>(wb, so0, f1);
+    add_base2<0, 0, 8>(wb, se1, f2);   add_base2<0, 1, 9>(wb, so1, f2);   add_base2<1, 2, 10>(wb, se1, f2);  add_base2<1, 3, 11>(wb, so1, f2);
+    add_base2<2, 0, 12>(wb, se1, f3);  add_base2<2, 1, 13>(wb, so1, f3);  add_base2<3, 2, 14>(wb, se1, f3);  add_base2<3, 3, 15>(wb, so1, f3);
+    return redo;
+}
+
+template <int W>
+__global__ void __launch_bounds__(F5_WAVES * 64, 2)
+k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
+        int reads_per_block) {
+    __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
+    __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
+    __shared__ uint32_t s_pwin[F5_WAVES][F5_REP * F5_REPW];           // per wave: packed counters, byte c of a word = base c (A C G T)
+    __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
+    __shared__ uint32_t s_ticket, s_gcur;
+    unsigned long long *const ctr = eb.ctr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t n = rd.n_reads;
+    const int64_t rb = (int64_t)blockIdx.x * reads_per_block;
+    const int64_t re = rb + reads_per_block < n ? rb + reads_per_block : n;
+    lds_u32 *const bwin = (lds_u32 *)s_bwin;
+    lds_u32 *const pwin = (lds_u32 *)s_pwin[wave];
+    for (int i = tid; i < F_BPL * F_BW; i += F5_WAVES * 64) bwin[i] = 0;
+    for (int i = lane; i < F5_REP * F5_REPW; i += 64) pwin[i] = 0;
+    // every nibble of the base staging buffer starts as a valid code (the bytes in front of a run are read by the
+    // lanes whose pieces start 8 bases early, and are never written again)
+    for (int i = lane; i < F5_SB / 4; i += 64) ((lds_u32 *)s_s[wave])[i] = 0x11111111u;
+    if (tid == 0) { s_ticket = 0; s_gcur = 0; }
+    if (tid == 0 && blockIdx.x == 0) { eb.ctr[26] = 0ull; eb.ctr[27] = 0ull; eb.ctr[28] = 0ull; }      // k_gcompact / k_long's counters (amp_wave.hpp)
+    int32_t bw_base = rb < n ? rd.pos[rb] : 0;
+    bw_base = (bw_base < 16 ? 0 : bw_base - 16) & ~15;
+    __syncthreads();
+
+    const int32_t mq = P.min_quality;
+    const uint32_t mqc = (uint32_t)(mq > 256 ? 256 : mq);
+    const uint32_t thr = mqc * (uint32_t)W;
+    const uint32_t mqb = (uint32_t)mq * 0x01010101u;             // mq <= 128 (the host sends other runs to the general kernel)
+    const uint32_t G = (uint32_t)P.ref_len;
+    const uint32_t n_tb = re > rb ? (uint32_t)((re - rb + 63) / 64) : 0u;
+    auto take_ticket = [&]() {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    unsigned long long n_err = 0;
+    // bank plan: lane l works on piece (k + l) mod np in step k, starts its pieces 8 bases early when bit 1 of l is
+    // set and adds into replica (l >> 2) & 3 (replica r is skewed by r banks)
+    const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
+    const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
+    const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F5_REPW * 4));
+    lds_u8 *const qst = (lds_u8 *)s_q[wave] + F5_PAD;
+    lds_u8 *const sst = (lds_u8 *)s_s[wave] + F5_PAD;
+    int32_t pw_base = 0;
+    int pw_tiles = F_FLUSH;
+    const unsigned ev_shard = blockIdx.x & (EV_SHARDS - 1);
+    amp_ins_event *const ev_list = eb.ev + (size_t)ev_shard * (size_t)eb.cap;
+    unsigned long long ev_base = 0;
+    uint32_t ev_left = 0;
+
+    // folds the wave's packed window into the block's 32-bit window (or the global table) and clears it
+    auto fold = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the adds of the counting phase are invisible to the compiler's wait counts)
+        wave_sync();
+#pragma unroll 1
+        for (int idx = lane; idx < F_PW; idx += 64) {
+            uint32_t ag = 0, ct = 0;                                 // A | G << 16, C | T << 16
+#pragma unroll
+            for (int r = 0; r < F5_REP; ++r) {
+                const uint32_t w = pwin[r * F5_REPW + idx];
+                pwin[r * F5_REPW + idx] = 0;
+                ag += w & 0x00FF00FFu; ct += (w >> 8) & 0x00FF00FFu;
+            }
+            if (ag | ct) {
+                const int32_t p = pw_base + idx;
+                const uint32_t d = (uint32_t)(p - bw_base);
+                const uint32_t c4[4] = {ag & 0xFFFFu, ct & 0xFFFFu, ag >> 16, ct >> 16};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!c4[c]) continue;
+                    if (d < (uint32_t)F_BW) lds_add(bwin + c * F_BW + d, c4[c]);
+                    else if ((uint32_t)p < G) atomicAdd(&counts[(size_t)p * AMP_NSYM + c], c4[c]);
+                }
+            }
+        }
+        wave_sync();
+    };
+    auto pad_events = [&]() {
+        if ((uint32_t)lane < ev_left && (long long)(ev_base + (unsigned)lane) < eb.cap) ev_list[ev_base + (unsigned)lane] = amp_ins_event{-1, 0u, 0, 0};
+    };
+
+    struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };      // as loaded
+    // ... and as kept: lf = l_seq (saturated at 0xFFFF) | paired << 16 | reverse << 17 | the template-length test of A:452 << 18 |
+    // number of CIGAR ops (saturated at 7) << 19 | lane holds a read of the block << 22
+    struct HdrP { int32_t pos; uint32_t lf, c0, o8;
+        __device__ uint32_t lseq() const { return lf & 0xFFFFu; }
+        __device__ uint32_t nops() const { return (lf >> 19) & 7u; }
+        __device__ uint32_t flag() const { return ((lf >> 16) & 1u) | (((lf >> 17) & 1u) << 4); }
+        __device__ bool isize_flag() const { return (lf >> 18) & 1u; }
+        __device__ bool valid() const { return (lf >> 22) & 1u; } };
+    auto load_hdr = [&](int64_t t0) {
+        Hdr h{0, 0, 0u, 0u, 0u, 0u, 0u};
+        const int64_t i = t0 + lane;
+        if (i < re) {
+            h.pos = rd.pos[i]; h.flag = rd.flag[i]; h.tlen = rd.tlen[i]; h.lseq = rd.lseq[i];
+            h.c0 = rd.cig_off32[i]; h.c1 = rd.cig_off32[i + 1]; h.o8 = rd.seq_off8[i];
+        }
+        return h;
+    };
+    auto pack_hdr = [&](const Hdr &h, int64_t t0) {
+        const uint32_t nn = h.c1 - h.c0, at = (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen);
+        const bool isz = ((int64_t)at - P.max_primer_len) > (int64_t)h.lseq;                                  // A:452
+        return HdrP{h.pos, (h.lseq > 0xFFFFu ? 0xFFFFu : h.lseq) | ((h.flag & 1u) << 16) | (((h.flag >> 4) & 1u) << 17) | ((isz ? 1u : 0u) << 18) |
+                               ((nn > 7u ? 7u : nn) << 19) | ((t0 + lane < re ? 1u : 0u) << 22), h.c0, h.o8};
+    };
+    struct Cg { uint32_t w[5]; };
+    auto load_cig = [&](const HdrP &h) {
+        Cg c{{0u, 0u, 0u, 0u, 0u}};
+        const uint32_t nops = h.nops();
+        if (nops >= 1u && nops <= 5u) {
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; ++k) c.w[k] = rd.cig[h.c0 + (k < nops ? k : 0u)];
+        }
+        return c;
+    };
+    // the tile's run: the bytes of its leading reads that fit the staging buffer (64 reads of up to 152 bases always do)
+    struct Geo { uint32_t np, row, Tq, m0; int ntake; bool solo, fastq; };
+    auto geometry = [&](const HdrP &h) {
+        Geo g;
+        const bool valid = h.valid();
+        const uint32_t hl = h.lseq();
+        const bool shortq = valid && hl >= 1u && hl <= (uint32_t)F5_MAXLEN;
+        g.np = shortq ? (hl + phi_lane + 15u) >> 4 : 1u;
+        g.m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.o8);
+        g.row = (h.o8 - g.m0) * 8u;
+        const uint32_t nch = (hl + 7u) >> 3;
+        // a row is read as pieces of 16 bytes plus the 8 bytes behind them: up to 24 bytes past the read's own padded bytes
+        const bool fits = valid && h.o8 >= g.m0 && (h.o8 - g.m0) <= (uint32_t)(F5_QRUN / 8) && g.row + 8u * nch <= (uint32_t)F5_QRUN;
+        const unsigned long long fitmask = __ballot(fits);
+        g.ntake = fitmask == ~0ull ? 64 : __builtin_ctzll(~fitmask);
+        g.solo = g.ntake == 0;
+        if (g.solo) g.ntake = 1;
+        g.Tq = g.solo ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)(g.row + 8u * nch), g.ntake - 1);
+        g.fastq = lane < g.ntake && !g.solo && shortq;
+        if (!g.fastq) { g.row = 0u; g.np = 1u; }
+        return g;
+    };
+    struct Shape { Cig2 s; bool ok; int32_t refspan; };
+    auto shape_of = [&](const HdrP &h, const Cg &c, bool fastq) {
+        Shape r;
+        r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+        const int nops = (int)h.nops();
+        r.ok = fastq && nops >= 1 && nops <= 5 && cig2_from_words5(nops, c.w, (int32_t)h.lseq(), r.s);
+        if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
+        if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+        r.refspan = r.ok ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : 1;
+        return r;
+    };
+    struct Tabs { int32_t L, R; };
+    auto load_tabs = [&](const HdrP &h, const Shape &sh) {
+        Tabs t{-1, -1};
+        const bool in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + sh.refspan - 1) < G;
+        if (sh.ok && P.do_trim && in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
+        return t;
+    };
+    // LDS-DMA of a run: lane l moves bytes [1024 s + 16 l, + 16) to the same offset of the staging buffer; lanes past the
+    // run re-read its end, lanes past the buffer do nothing
+    auto issue_run = [&](const uint8_t *run, uint32_t nbytes, lds_u8 *stage, int cap) {
+        const uint32_t last = nbytes ? (nbytes - 1u) & ~15u : 0u;
+#pragma unroll
+        for (int sl = 0; sl < (cap + 1023) / 1024; ++sl) {
+            uint32_t off = (uint32_t)(sl * 1024 + lane * 16);
+            if (sl * 1024 + 1024 <= cap || (int)off < cap) dma16(run + (off < last ? off : last), stage + sl * 1024);
+        }
+    };
+
+    uint32_t pw_lim = 0;
+
+    // ---- prologue: three tiles' headers; CIGAR words of the first two; the first tile's qualities and table entries -----------
+    uint32_t tk0 = take_ticket(), tk1 = take_ticket(), tk2 = take_ticket();
+    int64_t i0 = rb + 64 * (int64_t)tk0, i1 = rb + 64 * (int64_t)tk1, i2 = rb + 64 * (int64_t)tk2;
+    HdrP h0, h1;
+    Hdr hR;
+    {
+        const Hdr a = load_hdr(i0), b = load_hdr(i1);
+        hR = load_hdr(i2);
+        h0 = pack_hdr(a, i0); h1 = pack_hdr(b, i1);
+    }
+    Cg cN = load_cig(h1);
+    Geo g0 = geometry(h0);
+    Shape sh0;
+    {
+        const Cg c = load_cig(h0);
+        issue_run(rd.qual + (int64_t)g0.m0 * 8, g0.Tq, qst, F5_QRUN);
+        sh0 = shape_of(h0, c, g0.fastq);
+    }
+    Tabs tb0 = load_tabs(h0, sh0);
+    while (tk0 < n_tb) {
+        // ---- everything issued a phase or more ago has arrived: this tile's qualities and table entries, the next tile's
+        // CIGAR words, the header of the tile behind it -------------------------------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const HdrP h = h0;
+        const Geo g = g0;
+        const Shape shp = sh0;
+        const Tabs tA = tb0;
+        const Geo g1 = geometry(h1);
+        const Shape sh1 = shape_of(h1, cN, g1.fastq);
+        const HdrP h2 = pack_hdr(hR, i2);
+        // this tile's packed bases start moving (their buffer was in use until the end of the last tile)
+        issue_run(rd.seq + (int64_t)g.m0 * 4, g.Tq >> 1, sst, F5_QRUN / 2);
+        const int64_t i = i0 + lane;
+        const int32_t pos = h.pos;
+        const uint32_t lseq = h.lseq(), flag = h.flag(), c0 = h.c0, o8 = h.o8;
+        const uint32_t np = g.np, phi = g.fastq ? phi_lane : 0u;
+        const bool fastq = g.fastq;
+        // ---- the wave's packed window: fold and re-anchor when the tile has moved on, or before a byte could overflow
+        {
+            const int32_t first_pos = __builtin_amdgcn_readfirstlane(pos);
+            const int32_t want = (first_pos < 16 ? 0 : first_pos - 16) & ~15;
+            if (pw_tiles >= F_FLUSH || want < pw_base || want - pw_base >= 64) {
+                if (pw_tiles) fold();
+                pw_base = want; pw_tiles = 0;
+            }
+            ++pw_tiles;
+        }
+        pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+        // ---- pass over the qualities: slot k of the lane is piece (k + rot) mod np of its read; per piece 16 failing-window
+        // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality) and 16
+        // good-quality bits, kept as fo[k] = fail | ok << 16 ------------------------------------------------------------------
+        const uint32_t rot = (uint32_t)lane % np;
+        const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
+        const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
+        uint32_t fo[F5_NP];
+#pragma unroll
+        for (int k = 0; k < F5_NP; ++k) {
+            fo[k] = 0u;
+            if (!__ballot((uint32_t)k < np)) continue;                         // (uniform: no lane of the tile has that many pieces)
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
+            p = (uint32_t)k < np ? p : np - 1u;
+            const lds_u8 *src = qst + lrow + (int32_t)(p * 16u);
+            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
+            const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
+            const uint32_t fail = P.do_trim ? piece_fail_bits<W>(q, make_uint2(c.x, c.y), thr) : 0u;
+            fo[k] = fail | (ok_bits16(q, mqb) << 16);
+        }
+        const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
+        // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------
+        Cig2 s = shp.s;
+        const bool shaped = shp.ok;
+        const bool in_ref = (uint32_t)pos < G && (uint32_t)(pos + shp.refspan - 1) < G;          // A:450-451
+        const bool rev = (flag & 0x10u) != 0;
+        const int32_t q_ins = s.kind ? s.a + s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
+        TrimState ts{pos, 1, 0u, 0};
+        if (shaped && P.do_trim) {
+            if (!in_ref) ts.err = AMP_RS_INDEX_REF;
+            else cig2_trim_primers_isize(ts, flag, h.isize_flag(), (int32_t)lseq, s, tA.L, tA.R);
+        }
+        const bool scan = shaped && P.do_trim && !ts.err && !s.punt;
+        // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
+        int32_t lo = 0, qlen = 0;
+        if (scan) { cig2_quality_window(s, (int32_t)lseq, lo, qlen); lo += (int32_t)phi; }
+        const int32_t hi = lo + qlen;
+        // ---- first failing window start (forward) / last failing window end (reverse) inside [lo, hi) ---------------
+        int32_t ffmin = 0x7FFFFFFF, lemax = -1;
+        if (P.do_trim) {
+#pragma unroll
+            for (int k = 0; k < F5_NP; ++k) {
+                if (!__ballot((uint32_t)k < np)) continue;
+                uint32_t p = (uint32_t)k + rot;
+                p = p >= np ? p - np : p;
+                p = (uint32_t)k < np ? p : np;
+                const int32_t j0 = (int32_t)(p * 16u);
+                int32_t blo = lo - j0, bhi = hi - W - j0;                   // window starts j0+b must lie in [lo, hi - W]
+                blo = blo < 0 ? 0 : (blo > 16 ? 16 : blo); bhi = bhi > 15 ? 15 : (bhi < -1 ? -1 : bhi);
+                const uint32_t fail = (fo[k] & 0xFFFFu) & (0xFFFFu >> (15 - bhi)) & (0xFFFFu << blo);
+                const int32_t f1 = j0 + (__builtin_ffs((int)fail) - 1), e1 = j0 + (31 - __builtin_clz(fail)) + W;
+                ffmin = fail && f1 < ffmin ? f1 : ffmin;
+                lemax = fail && e1 > lemax ? e1 : lemax;
+            }
+        }
+        // ---- quality clip, results (A:589-686) ------------------------------------------------------------------
+        bool general = h.valid() && !shaped;               // (a lane whose bytes did not fit the run included)
+        bool stored = false;
+        uint32_t ncig = 0, cw[5] = {0u, 0u, 0u, 0u, 0u};
+        int32_t reflen = 0;
+        if (shaped) {
+            if ((fb & 0xFFu) == 0xFFu || s.punt) {
+                general = true;                   // QUAL '*': the generic code reports it (A:561-562, A:718); a shape the closed forms leave
+            } else {
+                if (scan) {
+                    int32_t iq;
+                    if (!rev && ffmin != 0x7FFFFFFF) iq = ffmin - lo;
+                    else if (rev && lemax >= 0) iq = lemax - lo;
+                    else {
+                        // no full window failed: the shrinking windows at the 3' end decide (A:575-576, A:637-638)
+                        iq = rev ? 0 : qlen;
+                        int32_t acc = 0;
+                        const int32_t kmax = qlen < W - 1 ? qlen : W - 1;
+                        const int32_t qlo = lo - (int32_t)phi, qhi = hi - (int32_t)phi;            // query indices
+                        for (int32_t k = 1; k <= kmax; ++k) {
+                            acc += (int32_t)lq[rev ? qlo + k - 1 : qhi - k];
+                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
+                        }
+                    }
+                    cig2_trim_quality(ts, rev, iq, qlen, s);
+                }
+                if (s.punt) {
+                    general = true;
+                } else {
+                    if (!ts.err) {
+                        const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op,
+                                                  ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D), ((uint32_t)s.m2 << 4) | s.op,
+                                                  ((uint32_t)s.c << 4) | OP_S};
+                        const bool has[5] = {s.a > 0, s.m1 > 0, s.kind != 0, s.kind != 0 && s.m2 > 0, s.c > 0};
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) {
+                            if (has[t]) {
+#pragma unroll
+                                for (int j = 0; j < 5; ++j) cw[j] = ncig == (uint32_t)j ? part[t] : cw[j];
+                                ++ncig;
+                            }
+                        }
+                        reflen = s.ref_len();
+                    }
+                    stored = true;
+                    if (ts.err) ++n_err;
+                }
+            }
+        }
+        const bool counted = stored && !ts.err && P.do_count;
+        // ---- what counting needs of the qualities besides the bits: the inserted bases' (A:730-748), and the good bits of
+        // GROUP B = the 16 bases from the 8-aligned start of the second segment, for the piece that holds bases of both
+        // segments of an indel read (its second part is counted on its own) --------------------------------------------
+        const bool two = counted && s.kind != 0;
+        const int32_t g_b = q_seg2 & ~7;
+        uint32_t good = 0, okB = 0;
+        if (__ballot(two)) {
+            if (two && s.kind == 1) {
+                uint32_t m = 0;
+                for (int32_t j = 0; j < s.k; ++j) m |= ((int32_t)lq[s.a + s.m1 + j] >= mq ? 1u : 0u) << j;      // (a clip may have taken the first inserted bases)
+                good = m;
+            }
+            if (two) {
+                const amp_u32x2 a = *(const lds_u32x2 *)(lq + g_b), b = *(const lds_u32x2 *)(lq + g_b + 8);
+                okB = ok_bits16(make_uint4(a.x, a.y, b.x, b.y), mqb);
+            }
+        }
+        // ---- the tile's bases have arrived; the quality buffer is free: the next tile's loads go out ---------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stored) {
+            uint32_t *home = out.new_cig + ((size_t)c0 + 3 * (size_t)i);
+            if (ncig > 0u) home[0] = cw[0];
+            if (ncig > 1u) home[1] = cw[1];
+            if (ncig > 2u) home[2] = cw[2];
+            if (ncig > 3u) home[3] = cw[3];
+            if (ncig > 4u) home[4] = cw[4];
+            if (out.new_pos) out.new_pos[i] = ts.pos;
+            if (out.new_ncig) out.new_ncig[i] = ncig;
+            if (out.ref_len) out.ref_len[i] = reflen;
+            if (out.trim_flags) out.trim_flags[i] = (uint8_t)(ts.err ? 0u : ts.flags);
+            if (out.status) out.status[i] = (uint8_t)ts.err;
+        }
+        const uint32_t tk3 = take_ticket();
+        const int64_t i3 = rb + 64 * (int64_t)tk3;
+        issue_run(rd.qual + (int64_t)g1.m0 * 8, g1.Tq, qst, F5_QRUN);
+        tb0 = load_tabs(h1, sh1);
+        cN = load_cig(h2);
+        hR = load_hdr(i3);
+        // pad nibbles of the staged rows (a row is padded to 8 bases) become a valid code: the test for codes outside
+        // A C G T looks at whole pieces
+        if (fastq) {
+            const uint32_t e = lseq & 7u;                                     // bases of the row's last group of 8 (0: the group is full)
+            if (e) {
+                lds_u32 *w = (lds_u32 *)(sst + (g.row >> 1) + 4u * (lseq >> 3));
+                // nibble i of the group sits in byte i >> 1, high nibble first
+                const uint32_t x = *w, xs = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);      // nibble i at bit 4 i
+                const uint32_t keep = (1u << (4u * e)) - 1u;
+                const uint32_t ys = (xs & keep) | (0x11111111u & ~keep);
+                *w = ((ys & 0x0F0F0F0Fu) << 4) | ((ys >> 4) & 0x0F0F0F0Fu);
+            }
+        }
+        wave_sync();
+
+        // ---- counting (A:709-753): the counted query ranges [qa1, qb1) and [qa2, qb2) in piece coordinates, the window
+        // offset of piece coordinate 0 for each of them ------------------------------------------------------------------
+        const int32_t qa1 = counted ? s.a + (int32_t)phi : 0, qb1 = counted ? qa1 + s.m1 : 0;
+        const int32_t qa2 = two ? qb1 + (s.kind == 1 ? s.k : 0) : qb1, qb2 = two ? qa2 + s.m2 : qa2;
+        const int32_t pos2 = ts.pos + s.m1 + (s.kind == 2 ? s.k : 0);              // reference position of the second segment
+        bool bad_extra = false;
+        // deletion: '-' at each of its positions (A:714-715), through the block's window
+        if (two && s.kind == 2) {
+            for (int32_t j = 0; j < s.k; ++j) {
+                const int32_t r = ts.pos + s.m1 + j;
+                const uint32_t d = (uint32_t)(r - bw_base);
+                if ((uint32_t)r >= G) bad_extra = true;
+                else if (d < (uint32_t)F_BW) lds_add_nt(bwin + 4 * F_BW + d, 1u);
+                else atomicAdd(&counts[(size_t)r * AMP_NSYM + 5], 1u);
+            }
+        }
+        // insertion (A:730-748): one event per maximal run of good-quality inserted bases
+        {
+            uint32_t runs = good & ~(good << 1);                              // first base of every run
+            const unsigned long long em = __ballot(runs != 0u);
+            if (em) {
+                const uint32_t total = (uint32_t)__popcll(em);
+                if (total > ev_left) {
+                    pad_events();
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(&ctr[16 + ev_shard], (unsigned long long)F_EVGRAN);
+                    ev_base = __shfl(nb, 0); ev_left = F_EVGRAN;
+                }
+                if (runs) {
+                    const int32_t q0 = s.a + s.m1, r2 = ts.pos + s.m1, ref_end = ts.pos + s.m1 + s.m2;
+                    const unsigned long long slot = ev_base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+                    const uint32_t rid = (uint32_t)(read_base + (uint64_t)i);
+                    bool firstrun = true;
+                    while (runs) {
+                        const int32_t js = __builtin_ctz(runs);
+                        runs &= runs - 1u;
+                        const int32_t je = js + __builtin_ctz(~(good >> js));
+                        int32_t elo, ehi;
+                        if (je == s.k && s.m2 > 0 && r2 == 0) py_slice(q0 + js, q0 + je + 1, (int32_t)lseq, elo, ehi);   // A:735-736
+                        else py_slice(q0 + js - 1, q0 + je, (int32_t)lseq, elo, ehi);              // A:738
+                        int32_t ins_pos = je == s.k ? r2 : ref_end;                                // A:742 / A:739-740
+                        ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                               // A:744
+                        const bool inside = (uint32_t)ins_pos < G;
+                        if (!inside) bad_extra = true;
+                        if (firstrun) {
+                            if ((long long)slot < eb.cap) ev_list[slot] = inside ? amp_ins_event{ins_pos, rid, elo, ehi} : amp_ins_event{-1, 0u, 0, 0};
+                            if (inside) {
+                                const uint32_t d = (uint32_t)(ins_pos - bw_base);
+                                if (d < (uint32_t)F_BW) lds_add_nt(bwin + 5 * F_BW + d, 1u);
+                                else atomicAdd(&eb.ins_at[ins_pos], 1u);
+                            }
+                        } else if (inside) {
+                            eb.record(ins_pos, rid, elo, ehi);
+                        }
+                        firstrun = false;
+                    }
+                }
+                ev_base += total; ev_left -= total;
+            }
+        }
+        uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F5_NP = group B
+        int32_t xbe = 0, jb = 0;
+        bool has_b = false;
+        if (two) {
+            const int32_t jstar = (qb1 - 1) & ~15;                   // the piece that holds the first segment's last base
+            has_b = jstar + 16 > qa2 && qb2 > qa2;
+            xbe = qb2 < jstar + 16 ? qb2 : jstar + 16;
+            jb = g_b + (int32_t)phi;
+        }
+        // The bases go into the wave's packed window, F_PW positions from pw_base; a tile whose reads lie further apart (the
+        // step from one pile of reads to the next) is counted in PASSES: fold, re-anchor at the first lane left.
+        const int32_t end_pos = two ? pos2 + s.m2 : ts.pos + s.m1;                 // one past the last counted position
+        const lds_u8 *const lsrow = sst + (int32_t)(g.row >> 1) - (int32_t)(phi >> 1);
+        bool todo = counted;
+        for (bool first_pass = true;; first_pass = false) {
+            const unsigned long long tm = __ballot(todo);
+            if (!tm) break;
+            const int lead = __builtin_ctzll(tm);
+            if (!first_pass) {
+                fold();
+                const int32_t lead_pos = __builtin_amdgcn_readlane(pos, lead);
+                pw_base = (lead_pos < 16 ? 0 : lead_pos - 16) & ~15; pw_tiles = 1;
+                pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+            }
+            const bool fits = ts.pos - pw_base >= 16 && end_pos - pw_base + 16 <= (int32_t)pw_lim;
+            const bool now = todo && (fits || lane == lead);
+            const int32_t a1 = now ? qa1 : 0, b1 = now ? qb1 : 0, a2 = now ? qa2 : 0, b2 = now ? qb2 : 0;
+            const int32_t dbase1 = ts.pos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
+            if (__ballot(has_b && now)) {
+                if (has_b && now) {
+                    const lds_u8 *sp = sst + (g.row >> 1) + (uint32_t)(g_b >> 1);
+                    const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+                    int32_t klo = qa2 - jb, khi = xbe - jb;
+                    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
+                    const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
+                    if (count_piece5(sq, okB & rng, dbase2 + jb, pw_lim, wrep)) redo |= 1u << F5_NP;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < F5_NP; ++k) {
+                if (!__ballot((uint32_t)k < np)) continue;
+                uint32_t p = (uint32_t)k + rot;
+                p = p >= np ? p - np : p;
+                const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
+                p = (uint32_t)k < np ? p : np;
+                const int32_t j0 = (int32_t)(p * 16u);
+                const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
+                const lds_u8 *sp = lsrow + pa * 8u;
+                const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+                int32_t klo = (second ? a2 : a1) - j0, khi = (second ? b2 : b1) - j0;
+                klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
+                const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);  // empty when khi <= klo
+                if (count_piece5(sq, (fo[k] >> 16) & rng, (second ? dbase2 : dbase1) + j0, pw_lim, wrep)) redo |= 1u << k;
+            }
+            todo = todo && !now;
+        }
+        bool want_status = bad_extra;
+        if (__ballot(redo != 0u)) {
+            // careful loop (rare): bases of the flagged pieces one by one, straight from memory into the 32-bit counters
+            if (redo) {
+                const uint8_t *qrow = rd.qual + (int64_t)o8 * 8;
+                const uint8_t *srow = rd.seq + (int64_t)o8 * 4;
+                const int32_t a1 = qa1 - (int32_t)phi, b1 = qb1 - (int32_t)phi, a2 = qa2 - (int32_t)phi, b2 = qb2 - (int32_t)phi;   // query indices
+                auto careful = [&](int32_t x0, int32_t x1, int32_t qa_q, int32_t rp0) {
+                    for (int32_t q = x0; q < x1; ++q) {
+                        if ((int32_t)qrow[q] < mq) continue;
+                        const uint32_t sb = srow[q >> 1];
+                        const uint32_t col = col_of_code((q & 1) ? (sb & 15u) : (sb >> 4));
+                        const int32_t rp = rp0 + (q - qa_q);
+                        const uint32_t d = (uint32_t)(rp - bw_base);
+                        if (col > 4u || (uint32_t)rp >= G) want_status = true;
+                        else if (d < (uint32_t)F_BW && col < (uint32_t)F_NPL) lds_add_nt(bwin + col * F_BW + d, 1u);
+                        else atomicAdd(&counts[(size_t)rp * AMP_NSYM + col], 1u);
+                    }
+                };
+                for (int k = 0; k < F5_NP; ++k) {
+                    if (!((redo >> k) & 1u)) continue;
+                    uint32_t p = (uint32_t)k + rot;
+                    p = p >= np ? p - np : p;
+                    const int32_t j0 = (int32_t)(p * 16u) - (int32_t)phi;
+                    const bool second = j0 + (int32_t)phi >= qb1;
+                    const int32_t sa = second ? a2 : a1, sb_ = second ? b2 : b1;
+                    careful(j0 < sa ? sa : j0, j0 + 16 < sb_ ? j0 + 16 : sb_, sa, second ? pos2 : ts.pos);
+                }
+                if ((redo >> F5_NP) & 1u) careful(a2, xbe - (int32_t)phi, a2, pos2);
+            }
+        }
+        // ---- hand-over to the general pass: the block's segment of the list -----------------------------------------------
+        {
+            const bool status_only = !general && counted && want_status;      // a base could not be counted: exact status wanted
+            const bool has = general || status_only;
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add((lds_u32 *)&s_gcur, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (has) glist[(size_t)rb + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i | (status_only ? GL_STATUS_ONLY : 0u);
+            }
+        }
+        // ---- next tile ------------------------------------------------------------------------------------------------
+        h0 = h1; h1 = h2; g0 = g1; sh0 = sh1;
+        i0 = i1; i1 = i2; i2 = i3; tk0 = tk1; tk1 = tk2; tk2 = tk3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the loads issued for a tile that does not exist)
+    pad_events();
+    if (pw_tiles && n_tb) fold();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < F_BPL * F_BW; i += F5_WAVES * 64) {
+        const uint32_t v = bwin[i];
+        if (v) {
+            const int pl = i / F_BW, d = i - pl * F_BW;
+            const uint32_t p = (uint32_t)(bw_base + d);
+            if (p < G) {
+                if (pl < F_NPL) atomicAdd(&counts[(size_t)p * AMP_NSYM + pl], v);
+                else if (pl == 4) atomicAdd(&counts[(size_t)p * AMP_NSYM + 5], v);      // '-'
+                else atomicAdd(&eb.ins_at[p], v);
+            }
+        }
+    }
+    if (n_err) atomicAdd(&ctr[2], n_err);
+    if (tid == 0) gcnt[blockIdx.x] = s_gcur;
+}
+
+static inline FastGrid fast5_grid(int64_t n_reads, int n_cu) {
+    int64_t rpb = (n_reads + (int64_t)n_cu - 1) / (int64_t)n_cu;
+    rpb = ((rpb + 63) / 64) * 64;
+    if (rpb < 2 * F5_WAVES * 64) rpb = 2 * F5_WAVES * 64;
+    return FastGrid{(n_reads + rpb - 1) / rpb, rpb};
+}
+
+static inline int fast5_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out, uint32_t *counts,
+                               const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, hipStream_t stream) {
+    const unsigned g = (unsigned)fg.grid, t = F5_WAVES * 64;
+    const int rpb = (int)fg.rpb;
+    switch (P.window) {
+        case 1: k_fast5<1><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 2: k_fast5<2><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 3: k_fast5<3><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 4: k_fast5<4><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 5: k_fast5<5><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 6: k_fast5<6><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        case 7: k_fast5<7><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+        default: k_fast5<8><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace amp

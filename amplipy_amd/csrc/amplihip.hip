@@ -20,6 +20,7 @@
 #include "amp_read.hpp"
 #include "amp_tile.hpp"
 #include "amp_fast.hpp"
+#include "amp_fast5.hpp"
 #include "amp_wave.hpp"
 
 using namespace amp;
@@ -82,7 +83,7 @@ struct amp_ctx {
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
-    int kernel_variant = 4;       // 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
+    int kernel_variant = 4;       // 5 = fast kernel (second generation) + general pass, 4 = its first generation, 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
                                   // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
     uint32_t phases = 0xFFu;       // always 0xFF in the shipped library; -DAMP_DEV builds can mask phases of the tile kernel (AMPLIHIP_PHASES)
@@ -923,7 +924,7 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
 #ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
-    if (v && v[0] >= '1' && v[0] <= '4') c->kernel_variant = v[0] - '0';
+    if (v && v[0] >= '1' && v[0] <= '5') c->kernel_variant = v[0] - '0';
     v = getenv("AMPLIHIP_PHASES");
     if (v) c->phases = (uint32_t)strtoul(v, nullptr, 0);
 #endif
@@ -974,6 +975,7 @@ int amp_ctx_bind_counts(amp_ctx *c, void *dev_counts) {
     c->d_counts = (uint32_t *)dev_counts;
     c->d_ins_at = c->d_counts + (size_t)c->ref_len * AMP_NSYM;
     c->own_counts = false;
+    c->call_pending = false;       // (calls begun on the old table are not calls of this one)
     return AMP_OK;
 }
 
@@ -994,8 +996,8 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
     return AMP_OK;
 }
 
-int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 = fast + general pass
-    if (!c || variant < 1 || variant > 4) return AMP_EINVAL;
+int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 / 5 = fast kernel (first / second generation) + general pass
+    if (!c || variant < 1 || variant > 5) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -1053,14 +1055,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
     // windows wider than a chunk take the serial scan of the general kernel, and the fast kernel's byte-parallel
     // quality test is written for min_quality <= 128: no fast pass for such runs
-    const int variant = (c->kernel_variant == 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : c->kernel_variant;
+    const int kv = (c->kernel_variant >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : c->kernel_variant;
+    const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
     const FastGrid fg = fast_grid(n, c->n_cu);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without
     // tiles would still have to be placed on a CU one after the other), tiles per block decided on the device
-    const int64_t gen_grid = std::min<int64_t>(tg.grid, 4 * (int64_t)c->n_cu);
+    const int64_t gen_grid = std::min<int64_t>(std::min<int64_t>(tg.grid, 4 * (int64_t)c->n_cu), 1024);      // (1024: the words of segfirst, one per block)
     const int64_t n_tiles_max = (n + TILE - 1) / TILE;
     const int64_t gen_tpb_max = (((n_tiles_max + gen_grid - 1) / gen_grid + T_WAVES - 1) / T_WAVES) * T_WAVES;
     const size_t dlist_words = std::max(((size_t)tg.grid + 1) * (size_t)tg.tpb, (size_t)(n_tiles_max + gen_tpb_max + T_WAVES)) * TILE;
@@ -1097,14 +1100,15 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        if (fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64) != 0) {
+        if ((kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream)
+                     : fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64)) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
         uint32_t *segfirst = (uint32_t *)geo + 4, *llist = segfirst + 1024, *lpos = llist + n;
         // the list stays in the fast kernel's per-block segments and the tile kernel indexes them itself -- one launch less --
         // unless k_long needs the dense list (to flag its reads in) or the fast kernel ran more blocks than the tile kernel's table holds
-        const bool direct = !long_kernel && fg.grid <= GL_MAXSEG && gen_grid <= 1024;
+        const bool direct = !long_kernel && fg.grid <= GL_MAXSEG;
         const ListSrc ls{direct ? glist : nullptr, direct ? gcnt : nullptr, (int)fg.grid, (int)fg.rpb, (uint32_t)gen_grid, segfirst, geo};
         // (ctr[26..28] -- k_long's list length, its chunk ticket, the entries left to the tile kernel -- are zeroed by the fast kernel)
         if (!direct) {
@@ -1232,6 +1236,7 @@ int amp_add_counts(amp_ctx *c, const uint32_t *counts) {
     if (!c || !counts) return AMP_EINVAL;
     Guard g(c);
     size_t n = (size_t)c->ref_len * AMP_NSYM;
+    c->call_pending = false;       // the table changes: calls begun earlier are for the table as it was
     HIPCHK(c, c->call_buf.ensure(n * 4));
     HIPCHK(c, hipMemcpyAsync(c->call_buf.p, counts, n * 4, hipMemcpyHostToDevice, c->stream));
     k_add_u32<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->d_counts, c->call_buf.as<uint32_t>(), (int64_t)n);
@@ -1336,6 +1341,7 @@ int amp_reduce(amp_ctx *c, void *comm, int root) {
     if (!c) return AMP_EINVAL;
     if (!comm) return AMP_OK;
     Guard g(c);
+    c->call_pending = false;       // the table changes: calls begun earlier are for the un-reduced table
     void *h = dlopen(nullptr, RTLD_NOW);
     void *f_red = h ? dlsym(h, "ncclReduce") : nullptr;
     void *f_all = h ? dlsym(h, "ncclAllReduce") : nullptr;
@@ -1488,7 +1494,7 @@ k_coordinate_helpers(int64_t n, const uint32_t *__restrict__ cig_off, uint32_t *
     Emitter<CigBuf<1>> e{CigBuf<1>{fixed + c0}};
     for (int k = 0; k < nops; ++k) { const uint32_t v = c.get(k); e.push(v & 15u, v >> 4); }
     fixed_n[i] = (uint32_t)e.finish();
-    status[i] = (uint8_t)(e1 ? e1 : e2);
+    status[i] = (uint8_t)((e1 & 15) | ((e2 & 15) << 4));      // one nibble per helper: the reference's get_pos_on_query returns before it touches later ops
 }
 
 int amp_coordinate_helpers(amp_ctx *c, int64_t n, const uint32_t *cig_off, const uint32_t *cig, const int32_t *ref_start,

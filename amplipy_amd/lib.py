@@ -14,7 +14,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamplihip.so")
+LIB_PATH = os.environ.get("AMPLIHIP_LIB") or os.path.join(_HERE, "libamplihip.so")      # (AMPLIHIP_LIB: another build of the same library, for A/B timing)
 _LIB = None
 
 EXPORTS = [

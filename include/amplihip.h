@@ -209,8 +209,9 @@ int amp_error_reads(amp_ctx *ctx, int64_t *n);
  *   pos_on_query_out[i] = get_pos_on_query(cigar_i, ref_pos[i], ref_start[i])        (AmpliPy.py:389-412)
  *   pos_on_ref_out[i]   = get_pos_on_ref(cigar_i, query_pos[i], ref_start[i])        (AmpliPy.py:363-386)
  *   fixed_cig[cig_off[i] ..] / fixed_n[i] = fix_cigar(cigar_i)                       (AmpliPy.py:415-423)
- * cig_off[n + 1] / cig as in amp_reads (32-bit offsets, BAM words); status[i] = amp_read_status (an op code >= 9 makes
- * the reference's table look-up fail).  Host pointers; synchronous. */
+ * cig_off[n + 1] / cig as in amp_reads (32-bit offsets, BAM words); status[i] = amp_read_status of get_pos_on_query in the
+ * low nibble and of get_pos_on_ref in the high nibble (an op code >= 9 makes the reference's table look-up fail in the helper
+ * that reaches it; fix_cigar consults no table and never fails).  Host pointers; synchronous. */
 int amp_coordinate_helpers(amp_ctx *ctx, int64_t n, const uint32_t *cig_off, const uint32_t *cig, const int32_t *ref_start,
                            const int32_t *ref_pos, const int32_t *query_pos, int32_t *pos_on_query_out, int32_t *pos_on_ref_out,
                            uint32_t *fixed_cig, uint32_t *fixed_n, uint8_t *status);
@@ -303,7 +304,10 @@ typedef struct amp_call_view {
 int amp_call_compact_view(amp_ctx *ctx, const amp_call_params *params, amp_call_view *out);
 /* Enqueue the work of amp_call_compact_view on the ctx stream without waiting (right behind amp_process_batch_device,
  * say): a following amp_call_compact_view with the same parameters only waits for it and hands the views out.  Lets a
- * caller with several contexts in flight keep the calling kernels of one step in front of the next step's reads. */
+ * caller with several contexts in flight keep the calling kernels of one step in front of the next step's reads.
+ * begin must come BEHIND the last update of the table: amp_process_batch[_device], amp_reset, amp_add_counts, amp_reduce
+ * and amp_ctx_bind_counts all cancel a begun call (the following view then computes afresh), so on several GPUs the order
+ * is process, amp_reduce, begin, view.  From begin onward the memory behind the previous view is being overwritten. */
 int amp_call_compact_begin(amp_ctx *ctx, const amp_call_params *params);
 /* Text of insertion events from a DEVICE-resident batch: text[off[e] .. off[e+1]) receives
  * SEQ[q_from:q_to] of event e (off[e+1]-off[e] must equal q_to-q_from). ev/off/text are host.

@@ -1,7 +1,7 @@
 """Summarise gpurun_out/<tag>/ from tools/prof_scan.sh: per-kernel average duration and counter totals per dispatch."""
 import csv, glob, os, sys, collections
 tag = sys.argv[1]
-base = os.path.join("gpurun_out", tag)
+base = tag if os.path.isdir(tag) else os.path.join("gpurun_out", tag)
 short = lambda n: n.split("(")[0].replace("void ", "")[:40]
 for f in glob.glob(os.path.join(base, "kt", "*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
@@ -16,4 +16,5 @@ for f in glob.glob(os.path.join(base, "pmc_*", "*counter_collection.csv")):
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
+        v = sorted(v)[len(v) // 2:] if len(v) > 2 else v        # (the first launch of a run is cold)
         print("   %-32s %16.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
