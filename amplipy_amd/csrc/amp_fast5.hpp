@@ -25,20 +25,28 @@
 #pragma once
 
 #include "amp_fast.hpp"
+#include "amp_bf.hpp"
 
 namespace amp {
 
-#ifndef AMP_F5_WAVES
-#define AMP_F5_WAVES 8
+#ifndef AMP_F5_ABL
+#define AMP_F5_ABL 0      // development builds: parts of the kernel switched off to count the rest's instructions (results are wrong on purpose)
 #endif
-constexpr int F5_WAVES = AMP_F5_WAVES;    // waves per block, one block per CU
 constexpr int F5_NP = 20;                 // 16-base pieces of the longest read taken
 constexpr int F5_MAXLEN = 304;            // F5_NP pieces cover it from 8 bases before its start
-constexpr int F5_QRUN = 9728;             // quality bytes of a tile's run (64 reads of 152 padded bases)
 constexpr int F5_PAD = 16;                // bytes in front of / behind a staged run
-constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
-constexpr int F5_REP = 4;                 // replicas of a wave's packed window (bank conflicts of two cost nothing: the
-constexpr int F5_REPW = F_PW + 1;         // LDS takes four cycles to receive an atomic's operands)
+// Three builds of the kernel (template parameters WAVES, QRUN, REP; one block per CU, all of its LDS):
+//   8 waves, runs of 9,728 quality bytes (64 reads of up to 152 padded bases: every tile of a 150 bp run fits), packed
+//     windows of 256 positions in 4 replicas
+//   6 waves, runs of 13,312 bytes (64 reads of 208 padded bases on average), windows of 512 positions (a read of 300 bases
+//     does not fit 256) in 2 replicas
+//   4 waves, runs of 19,456 bytes (64 reads of 304 padded bases: every tile of reads the kernel takes fits), 512 positions
+//     in 4 replicas
+// The host picks by the batch's mean padded read length; reads of a tile that do not fit its run go to the general pass.
+// A counter byte gets at most 64 / REP increments per tile (a read covers a position once): the window is folded every
+// 255 / (64 / REP) tiles at the latest.
+// (Four replicas instead of variant 4's eight: two-way bank conflicts cost nothing, the LDS takes four cycles to receive an
+// atomic's operands anyway.)
 
 // bit 7 of every byte: quality >= mq (mq <= 128, mqb = mq in every byte); three instructions
 __device__ __forceinline__ uint32_t ok80(uint32_t q, uint32_t mqb) {
@@ -79,9 +87,10 @@ __device__ __forceinline__ void dma16(const void *g, const lds_u8 *l) {
 // One piece (16 bases): packed codes sq, counted-base bits m16 (bit b: base b of the piece is inside the counted range
 // and good enough), window offset d0 of its base 0, against the lane's replica of the wave's packed window.
 // Returns true when the careful loop has to redo the piece (a code outside A C G T in it, or it leaves the window).
-__device__ __forceinline__ bool count_piece5(const uint2 &sq, uint32_t m16, int32_t d0, uint32_t pw_lim, uint32_t wrep) {
-    const bool inwin = pw_lim >= 16u && (uint32_t)d0 <= pw_lim - 16u;
-    const bool redo = m16 != 0u && (!inwin || nibbles_bad(sq.x, sq.y) != 0u);
+__device__ __forceinline__ uint32_t count_piece5(const uint2 &sq, uint32_t m16, int32_t d0, int32_t lim16, uint32_t wrep) {
+    // (bit operations on purpose: with && / || the compiler branches around the tests)
+    const bool inwin = (d0 >= 0) & (d0 <= lim16);                       // lim16 = the window's width - 16 (negative: nothing fits)
+    const bool redo = (m16 != 0u) & (!inwin | (nibbles_bad(sq.x, sq.y) != 0u));
     const uint32_t m = redo ? 0u : m16;
     // shift counts of the even / odd bases of each half (the high nibble of a byte is the even base)
     const uint32_t se0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.x >> 4) & 0x07070707u);
@@ -94,13 +103,32 @@ __device__ __forceinline__ bool count_piece5(const uint2 &sq, uint32_t m16, int3
     add_base2<2, 0, 4>(wb, se0, f1);   add_base2<2, 1, 5>(wb, so0, f1);   add_base2<3, 2, 6>(wb, se0, f1);   add_base2<3, 3, 7>(wb, so0, f1);
     add_base2<0, 0, 8>(wb, se1, f2);   add_base2<0, 1, 9>(wb, so1, f2);   add_base2<1, 2, 10>(wb, se1, f2);  add_base2<1, 3, 11>(wb, so1, f2);
     add_base2<2, 0, 12>(wb, se1, f3);  add_base2<2, 1, 13>(wb, so1, f3);  add_base2<3, 2, 14>(wb, se1, f3);  add_base2<3, 3, 15>(wb, so1, f3);
-    return redo;
+    return redo ? 1u : 0u;
+}
+// bits [klo, khi) of a 16-bit mask, klo / khi clamped to 0..16
+__device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
+    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
+    return ((1u << khi) - 1u) & ~((1u << klo) - 1u);                    // empty when khi <= klo
+}
+// OR over the lanes of the wave (DPP row shifts and row broadcasts; the result is uniform)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+    uint32_t t = x;
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xF, 0xF, true);      // row_shr:1
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xF, 0xF, true);      // row_shr:2
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, true);      // row_shr:4
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, true);      // row_shr:8
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
 }
 
-template <int W>
+template <int W, int F5_WAVES, int F5_QRUN, int F5_REP, int F5_PW>
 __global__ void __launch_bounds__(F5_WAVES * 64, 2)
 k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
         int reads_per_block) {
+    constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
+    constexpr int F5_FLUSH = 255 / (64 / F5_REP);
+    constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
     __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
     __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
     __shared__ uint32_t s_pwin[F5_WAVES][F5_REP * F5_REPW];           // per wave: packed counters, byte c of a word = base c (A C G T)
@@ -135,7 +163,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     };
-    unsigned long long n_err = 0;
+    uint32_t n_err = 0;
     // bank plan: lane l works on piece (k + l) mod np in step k, starts its pieces 8 bases early when bit 1 of l is
     // set and adds into replica (l >> 2) & 3 (replica r is skewed by r banks)
     const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
@@ -144,7 +172,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
     lds_u8 *const qst = (lds_u8 *)s_q[wave] + F5_PAD;
     lds_u8 *const sst = (lds_u8 *)s_s[wave] + F5_PAD;
     int32_t pw_base = 0;
-    int pw_tiles = F_FLUSH;
+    int pw_tiles = F5_FLUSH;
     const unsigned ev_shard = blockIdx.x & (EV_SHARDS - 1);
     amp_ins_event *const ev_list = eb.ev + (size_t)ev_shard * (size_t)eb.cap;
     unsigned long long ev_base = 0;
@@ -155,7 +183,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the adds of the counting phase are invisible to the compiler's wait counts)
         wave_sync();
 #pragma unroll 1
-        for (int idx = lane; idx < F_PW; idx += 64) {
+        for (int idx = lane; idx < F5_PW; idx += 64) {
             uint32_t ag = 0, ct = 0;                                 // A | G << 16, C | T << 16
 #pragma unroll
             for (int r = 0; r < F5_REP; ++r) {
@@ -237,22 +265,20 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         if (!g.fastq) { g.row = 0u; g.np = 1u; }
         return g;
     };
-    struct Shape { Cig2 s; bool ok; int32_t refspan; };
+    struct Shape { Bf s; bool ok; int32_t refspan; };
     auto shape_of = [&](const HdrP &h, const Cg &c, bool fastq) {
         Shape r;
-        r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
-        const int nops = (int)h.nops();
-        r.ok = fastq && nops >= 1 && nops <= 5 && cig2_from_words5(nops, c.w, (int32_t)h.lseq(), r.s);
-        if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
-        if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
-        r.refspan = r.ok ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : 1;
+        bool ok;
+        r.s = bf_from_words5((int)h.nops(), c.w[0], c.w[1], c.w[2], c.w[3], c.w[4], (int32_t)h.lseq(), F_MAXINS, F_MAXDEL, ok);
+        r.ok = ok & fastq;
+        r.refspan = r.ok ? r.s.m1 + r.s.m2 + r.s.kD() : 1;
         return r;
     };
     struct Tabs { int32_t L, R; };
     auto load_tabs = [&](const HdrP &h, const Shape &sh) {
         Tabs t{-1, -1};
-        const bool in_ref = (uint32_t)h.pos < G && (uint32_t)(h.pos + sh.refspan - 1) < G;
-        if (sh.ok && P.do_trim && in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
+        const bool in_ref = ((uint32_t)h.pos < G) & ((uint32_t)(h.pos + sh.refspan - 1) < G);
+        if (sh.ok & (P.do_trim != 0) & in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
         return t;
     };
     // LDS-DMA of a run: lane l moves bytes [1024 s + 16 l, + 16) to the same offset of the staging buffer; lanes past the
@@ -309,24 +335,25 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         {
             const int32_t first_pos = __builtin_amdgcn_readfirstlane(pos);
             const int32_t want = (first_pos < 16 ? 0 : first_pos - 16) & ~15;
-            if (pw_tiles >= F_FLUSH || want < pw_base || want - pw_base >= 64) {
+            if (pw_tiles >= F5_FLUSH || want < pw_base || want - pw_base >= 64) {
                 if (pw_tiles) fold();
                 pw_base = want; pw_tiles = 0;
             }
             ++pw_tiles;
         }
-        pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+        pw_lim = (int64_t)G - pw_base >= (int64_t)F5_PW ? (uint32_t)F5_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
         // ---- pass over the qualities: slot k of the lane is piece (k + rot) mod np of its read; per piece 16 failing-window
         // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality) and 16
         // good-quality bits, kept as fo[k] = fail | ok << 16 ------------------------------------------------------------------
         const uint32_t rot = (uint32_t)lane % np;
+        const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
         const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
         const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
         uint32_t fo[F5_NP];
 #pragma unroll
         for (int k = 0; k < F5_NP; ++k) {
             fo[k] = 0u;
-            if (!__ballot((uint32_t)k < np)) continue;                         // (uniform: no lane of the tile has that many pieces)
+            if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;                                 // (uniform)
             uint32_t p = (uint32_t)k + rot;
             p = p >= np ? p - np : p;
             p = (uint32_t)k < np ? p : np - 1u;
@@ -337,121 +364,110 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             fo[k] = fail | (ok_bits16(q, mqb) << 16);
         }
         const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
-        // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------
-        Cig2 s = shp.s;
+        // ---- primer clips in closed form (A:450-558), branch-free (amp_bf.hpp) --------------------------------------
         const bool shaped = shp.ok;
-        const bool in_ref = (uint32_t)pos < G && (uint32_t)(pos + shp.refspan - 1) < G;          // A:450-451
+        const bool in_ref = ((uint32_t)pos < G) & ((uint32_t)(pos + shp.refspan - 1) < G);      // A:450-451
         const bool rev = (flag & 0x10u) != 0;
-        const int32_t q_ins = s.kind ? s.a + s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
-        TrimState ts{pos, 1, 0u, 0};
-        if (shaped && P.do_trim) {
-            if (!in_ref) ts.err = AMP_RS_INDEX_REF;
-            else cig2_trim_primers_isize(ts, flag, h.isize_flag(), (int32_t)lseq, s, tA.L, tA.R);
+        const bool trim = shaped & (P.do_trim != 0);
+        const int terr = (trim & !in_ref) ? AMP_RS_INDEX_REF : 0;
+        const bool use = trim & in_ref;
+        int32_t tpos = pos;
+        uint32_t tflags = 0u;
+        Bf s = shp.s;
+        {
+            int32_t p2 = pos; uint32_t f2 = 0u;
+            const Bf sp = bf_trim_primers(s, p2, f2, flag, h.isize_flag(), (int32_t)lseq, tA.L, tA.R);
+            if (!(AMP_F5_ABL & 16)) { s = bf_pick(use, sp, s); tpos = use ? p2 : pos; tflags = use ? f2 : 0u; }
         }
-        const bool scan = shaped && P.do_trim && !ts.err && !s.punt;
+        const bool scan = use & !s.punt;
         // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
-        int32_t lo = 0, qlen = 0;
-        if (scan) { cig2_quality_window(s, (int32_t)lseq, lo, qlen); lo += (int32_t)phi; }
+        int32_t lo, qlen;
+        bf_quality_window(s, (int32_t)lseq, lo, qlen);
+        lo = scan ? lo + (int32_t)phi : 0; qlen = scan ? qlen : 0;
         const int32_t hi = lo + qlen;
         // ---- first failing window start (forward) / last failing window end (reverse) inside [lo, hi) ---------------
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
-        if (P.do_trim) {
+        if (P.do_trim && !(AMP_F5_ABL & 8)) {
 #pragma unroll
             for (int k = 0; k < F5_NP; ++k) {
-                if (!__ballot((uint32_t)k < np)) continue;
+                if (!((live >> k) & 1u)) continue;
                 uint32_t p = (uint32_t)k + rot;
                 p = p >= np ? p - np : p;
                 p = (uint32_t)k < np ? p : np;
                 const int32_t j0 = (int32_t)(p * 16u);
-                int32_t blo = lo - j0, bhi = hi - W - j0;                   // window starts j0+b must lie in [lo, hi - W]
-                blo = blo < 0 ? 0 : (blo > 16 ? 16 : blo); bhi = bhi > 15 ? 15 : (bhi < -1 ? -1 : bhi);
-                const uint32_t fail = (fo[k] & 0xFFFFu) & (0xFFFFu >> (15 - bhi)) & (0xFFFFu << blo);
+                const uint32_t fail = (fo[k] & 0xFFFFu) & range_bits16(lo - j0, hi - W - j0 + 1);      // window starts j0+b must lie in [lo, hi - W]
                 const int32_t f1 = j0 + (__builtin_ffs((int)fail) - 1), e1 = j0 + (31 - __builtin_clz(fail)) + W;
-                ffmin = fail && f1 < ffmin ? f1 : ffmin;
-                lemax = fail && e1 > lemax ? e1 : lemax;
+                ffmin = ((fail != 0u) & (f1 < ffmin)) ? f1 : ffmin;
+                lemax = ((fail != 0u) & (e1 > lemax)) ? e1 : lemax;
             }
         }
-        // ---- quality clip, results (A:589-686) ------------------------------------------------------------------
-        bool general = h.valid() && !shaped;               // (a lane whose bytes did not fit the run included)
-        bool stored = false;
-        uint32_t ncig = 0, cw[5] = {0u, 0u, 0u, 0u, 0u};
-        int32_t reflen = 0;
-        if (shaped) {
-            if ((fb & 0xFFu) == 0xFFu || s.punt) {
-                general = true;                   // QUAL '*': the generic code reports it (A:561-562, A:718); a shape the closed forms leave
-            } else {
-                if (scan) {
-                    int32_t iq;
-                    if (!rev && ffmin != 0x7FFFFFFF) iq = ffmin - lo;
-                    else if (rev && lemax >= 0) iq = lemax - lo;
-                    else {
-                        // no full window failed: the shrinking windows at the 3' end decide (A:575-576, A:637-638)
-                        iq = rev ? 0 : qlen;
-                        int32_t acc = 0;
-                        const int32_t kmax = qlen < W - 1 ? qlen : W - 1;
-                        const int32_t qlo = lo - (int32_t)phi, qhi = hi - (int32_t)phi;            // query indices
-                        for (int32_t k = 1; k <= kmax; ++k) {
-                            acc += (int32_t)lq[rev ? qlo + k - 1 : qhi - k];
-                            if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
-                        }
-                    }
-                    cig2_trim_quality(ts, rev, iq, qlen, s);
-                }
-                if (s.punt) {
-                    general = true;
-                } else {
-                    if (!ts.err) {
-                        const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op,
-                                                  ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D), ((uint32_t)s.m2 << 4) | s.op,
-                                                  ((uint32_t)s.c << 4) | OP_S};
-                        const bool has[5] = {s.a > 0, s.m1 > 0, s.kind != 0, s.kind != 0 && s.m2 > 0, s.c > 0};
+        // ---- quality clip (A:589-686) --------------------------------------------------------------------------------
+        int32_t iq = rev ? 0 : qlen;
+        {
+            // the shrinking windows at the 3' end decide when no full window failed (A:575-576, A:637-638)
+            int32_t acc = 0;
+            const int32_t kmax = qlen < W - 1 ? qlen : W - 1;
+            const int32_t qlo = lo - (int32_t)phi, qhi = hi - (int32_t)phi;            // query indices
 #pragma unroll
-                        for (int t = 0; t < 5; ++t) {
-                            if (has[t]) {
-#pragma unroll
-                                for (int j = 0; j < 5; ++j) cw[j] = ncig == (uint32_t)j ? part[t] : cw[j];
-                                ++ncig;
-                            }
-                        }
-                        reflen = s.ref_len();
-                    }
-                    stored = true;
-                    if (ts.err) ++n_err;
-                }
+            for (int32_t k = 1; k <= W - 1; ++k) {
+                const bool on = k <= kmax;
+                const int32_t idx = on ? (rev ? qlo + k - 1 : qhi - k) : 0;
+                acc += on ? (int32_t)lq[idx] : 0;
+                iq = (on & ((int64_t)acc < (int64_t)mq * k)) ? (rev ? k : qlen - k) : iq;
             }
+            iq = (!rev & (ffmin != 0x7FFFFFFF)) ? ffmin - lo : iq;
+            iq = (rev & (lemax >= 0)) ? lemax - lo : iq;
         }
-        const bool counted = stored && !ts.err && P.do_count;
+        {
+            uint32_t f2 = tflags;
+            const Bf sq_ = bf_trim_quality(s, tpos, f2, rev, iq, qlen);
+            if (!(AMP_F5_ABL & 16)) { s = bf_pick(scan, sq_, s); tflags = scan ? f2 : tflags; }
+        }
+        // ---- results ---------------------------------------------------------------------------------------------------
+        const bool nogo = ((fb & 0xFFu) == 0xFFu) | (s.punt != 0u);               // QUAL '*': the generic code reports it (A:561-562, A:718); a shape the closed forms leave
+        const bool general = h.valid() & (!shaped | nogo);                       // (a lane whose bytes did not fit the run included)
+        const bool stored = shaped & !nogo;
+        const bool okres = stored & (terr == 0);
+        const int32_t reflen = okres ? s.ref_len() : 0;
+        n_err += (stored & (terr != 0)) ? 1u : 0u;
+        const bool counted = okres & (P.do_count != 0);
         // ---- what counting needs of the qualities besides the bits: the inserted bases' (A:730-748), and the good bits of
         // GROUP B = the 16 bases from the 8-aligned start of the second segment, for the piece that holds bases of both
         // segments of an indel read (its second part is counted on its own) --------------------------------------------
-        const bool two = counted && s.kind != 0;
-        const int32_t g_b = q_seg2 & ~7;
+        const bool two = counted & (s.kind != 0);
+        const int32_t q_seg2 = s.a + s.m1 + s.kI();
+        const int32_t g_b = two ? q_seg2 & ~7 : 0;
         uint32_t good = 0, okB = 0;
         if (__ballot(two)) {
-            if (two && s.kind == 1) {
+            if (two & (s.kind == 1)) {
                 uint32_t m = 0;
                 for (int32_t j = 0; j < s.k; ++j) m |= ((int32_t)lq[s.a + s.m1 + j] >= mq ? 1u : 0u) << j;      // (a clip may have taken the first inserted bases)
                 good = m;
             }
-            if (two) {
-                const amp_u32x2 a = *(const lds_u32x2 *)(lq + g_b), b = *(const lds_u32x2 *)(lq + g_b + 8);
-                okB = ok_bits16(make_uint4(a.x, a.y, b.x, b.y), mqb);
-            }
+            const amp_u32x2 a = *(const lds_u32x2 *)(lq + g_b), b = *(const lds_u32x2 *)(lq + g_b + 8);
+            okB = ok_bits16(make_uint4(a.x, a.y, b.x, b.y), mqb);
         }
-        // ---- the tile's bases have arrived; the quality buffer is free: the next tile's loads go out ---------------------
+        // ---- the tile's bases have arrived; the quality buffer is free: results out, the next tile's loads go out ------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (stored) {
+        {
+            // [S a][op m1][I|D k][op m2][S c], absent parts left out
+            const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op, ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D),
+                                      ((uint32_t)s.m2 << 4) | s.op, ((uint32_t)s.c << 4) | OP_S};
+            const bool has[5] = {bool(okres & (s.a > 0)), bool(okres & (s.m1 > 0)), bool(okres & (s.kind != 0)), bool(okres & (s.kind != 0) & (s.m2 > 0)), bool(okres & (s.c > 0))};
             uint32_t *home = out.new_cig + ((size_t)c0 + 3 * (size_t)i);
-            if (ncig > 0u) home[0] = cw[0];
-            if (ncig > 1u) home[1] = cw[1];
-            if (ncig > 2u) home[2] = cw[2];
-            if (ncig > 3u) home[3] = cw[3];
-            if (ncig > 4u) home[4] = cw[4];
-            if (out.new_pos) out.new_pos[i] = ts.pos;
-            if (out.new_ncig) out.new_ncig[i] = ncig;
-            if (out.ref_len) out.ref_len[i] = reflen;
-            if (out.trim_flags) out.trim_flags[i] = (uint8_t)(ts.err ? 0u : ts.flags);
-            if (out.status) out.status[i] = (uint8_t)ts.err;
+            uint32_t nc = 0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (has[t]) home[nc] = part[t];
+                nc += has[t] ? 1u : 0u;
+            }
+            if (stored) {
+                if (out.new_pos) out.new_pos[i] = tpos;
+                if (out.new_ncig) out.new_ncig[i] = nc;
+                if (out.ref_len) out.ref_len[i] = reflen;
+                if (out.trim_flags) out.trim_flags[i] = (uint8_t)(terr ? 0u : tflags);
+                if (out.status) out.status[i] = (uint8_t)terr;
+            }
         }
         const uint32_t tk3 = take_ticket();
         const int64_t i3 = rb + 64 * (int64_t)tk3;
@@ -461,8 +477,8 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         hR = load_hdr(i3);
         // pad nibbles of the staged rows (a row is padded to 8 bases) become a valid code: the test for codes outside
         // A C G T looks at whole pieces
-        if (fastq) {
-            const uint32_t e = lseq & 7u;                                     // bases of the row's last group of 8 (0: the group is full)
+        {
+            const uint32_t e = fastq ? lseq & 7u : 0u;                        // bases of the row's last group of 8 (0: the group is full)
             if (e) {
                 lds_u32 *w = (lds_u32 *)(sst + (g.row >> 1) + 4u * (lseq >> 3));
                 // nibble i of the group sits in byte i >> 1, high nibble first
@@ -477,13 +493,13 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         // ---- counting (A:709-753): the counted query ranges [qa1, qb1) and [qa2, qb2) in piece coordinates, the window
         // offset of piece coordinate 0 for each of them ------------------------------------------------------------------
         const int32_t qa1 = counted ? s.a + (int32_t)phi : 0, qb1 = counted ? qa1 + s.m1 : 0;
-        const int32_t qa2 = two ? qb1 + (s.kind == 1 ? s.k : 0) : qb1, qb2 = two ? qa2 + s.m2 : qa2;
-        const int32_t pos2 = ts.pos + s.m1 + (s.kind == 2 ? s.k : 0);              // reference position of the second segment
+        const int32_t qa2 = two ? qb1 + s.kI() : qb1, qb2 = two ? qa2 + s.m2 : qa2;
+        const int32_t pos2 = tpos + s.m1 + s.kD();                                 // reference position of the second segment
         bool bad_extra = false;
         // deletion: '-' at each of its positions (A:714-715), through the block's window
-        if (two && s.kind == 2) {
+        if (two & (s.kind == 2) & !(AMP_F5_ABL & 4)) {
             for (int32_t j = 0; j < s.k; ++j) {
-                const int32_t r = ts.pos + s.m1 + j;
+                const int32_t r = tpos + s.m1 + j;
                 const uint32_t d = (uint32_t)(r - bw_base);
                 if ((uint32_t)r >= G) bad_extra = true;
                 else if (d < (uint32_t)F_BW) lds_add_nt(bwin + 4 * F_BW + d, 1u);
@@ -492,7 +508,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         }
         // insertion (A:730-748): one event per maximal run of good-quality inserted bases
         {
-            uint32_t runs = good & ~(good << 1);                              // first base of every run
+            uint32_t runs = (AMP_F5_ABL & 4) ? 0u : good & ~(good << 1);                              // first base of every run
             const unsigned long long em = __ballot(runs != 0u);
             if (em) {
                 const uint32_t total = (uint32_t)__popcll(em);
@@ -503,7 +519,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                     ev_base = __shfl(nb, 0); ev_left = F_EVGRAN;
                 }
                 if (runs) {
-                    const int32_t q0 = s.a + s.m1, r2 = ts.pos + s.m1, ref_end = ts.pos + s.m1 + s.m2;
+                    const int32_t q0 = s.a + s.m1, r2 = tpos + s.m1, ref_end = tpos + s.m1 + s.m2;
                     const unsigned long long slot = ev_base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
                     const uint32_t rid = (uint32_t)(read_base + (uint64_t)i);
                     bool firstrun = true;
@@ -535,17 +551,14 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             }
         }
         uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F5_NP = group B
-        int32_t xbe = 0, jb = 0;
-        bool has_b = false;
-        if (two) {
-            const int32_t jstar = (qb1 - 1) & ~15;                   // the piece that holds the first segment's last base
-            has_b = jstar + 16 > qa2 && qb2 > qa2;
-            xbe = qb2 < jstar + 16 ? qb2 : jstar + 16;
-            jb = g_b + (int32_t)phi;
-        }
+        // group B: the part of the second segment that shares a piece with the first
+        const int32_t jstar = (qb1 - 1) & ~15;                       // the piece that holds the first segment's last base
+        const bool has_b = two & (jstar + 16 > qa2) & (qb2 > qa2);
+        const int32_t xbe = qb2 < jstar + 16 ? qb2 : jstar + 16;
+        const int32_t jb = g_b + (int32_t)phi;
         // The bases go into the wave's packed window, F_PW positions from pw_base; a tile whose reads lie further apart (the
         // step from one pile of reads to the next) is counted in PASSES: fold, re-anchor at the first lane left.
-        const int32_t end_pos = two ? pos2 + s.m2 : ts.pos + s.m1;                 // one past the last counted position
+        const int32_t end_pos = two ? pos2 + s.m2 : tpos + s.m1;                   // one past the last counted position
         const lds_u8 *const lsrow = sst + (int32_t)(g.row >> 1) - (int32_t)(phi >> 1);
         bool todo = counted;
         for (bool first_pass = true;; first_pass = false) {
@@ -556,25 +569,22 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 fold();
                 const int32_t lead_pos = __builtin_amdgcn_readlane(pos, lead);
                 pw_base = (lead_pos < 16 ? 0 : lead_pos - 16) & ~15; pw_tiles = 1;
-                pw_lim = (int64_t)G - pw_base >= (int64_t)F_PW ? (uint32_t)F_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
+                pw_lim = (int64_t)G - pw_base >= (int64_t)F5_PW ? (uint32_t)F5_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
             }
-            const bool fits = ts.pos - pw_base >= 16 && end_pos - pw_base + 16 <= (int32_t)pw_lim;
-            const bool now = todo && (fits || lane == lead);
+            const int32_t lim16 = (int32_t)pw_lim - 16;
+            const bool fits = (tpos - pw_base >= 16) & (end_pos - pw_base + 16 <= (int32_t)pw_lim);
+            const bool now = todo & (fits | (lane == lead));
             const int32_t a1 = now ? qa1 : 0, b1 = now ? qb1 : 0, a2 = now ? qa2 : 0, b2 = now ? qb2 : 0;
-            const int32_t dbase1 = ts.pos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
-            if (__ballot(has_b && now)) {
-                if (has_b && now) {
-                    const lds_u8 *sp = sst + (g.row >> 1) + (uint32_t)(g_b >> 1);
-                    const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
-                    int32_t klo = qa2 - jb, khi = xbe - jb;
-                    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
-                    const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
-                    if (count_piece5(sq, okB & rng, dbase2 + jb, pw_lim, wrep)) redo |= 1u << F5_NP;
-                }
+            const int32_t dbase1 = tpos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
+            if (__ballot(has_b & now)) {
+                const lds_u8 *sp = sst + (g.row >> 1) + (uint32_t)(g_b >> 1);
+                const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+                const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
+                redo |= count_piece5(sq, mB, dbase2 + jb, lim16, wrep) << F5_NP;
             }
 #pragma unroll
             for (int k = 0; k < F5_NP; ++k) {
-                if (!__ballot((uint32_t)k < np)) continue;
+                if (!((live >> k) & 1u) || (AMP_F5_ABL & 2)) continue;
                 uint32_t p = (uint32_t)k + rot;
                 p = p >= np ? p - np : p;
                 const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
@@ -583,12 +593,10 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
                 const lds_u8 *sp = lsrow + pa * 8u;
                 const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
-                int32_t klo = (second ? a2 : a1) - j0, khi = (second ? b2 : b1) - j0;
-                klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
-                const uint32_t rng = ((1u << khi) - 1u) & ~((1u << klo) - 1u);  // empty when khi <= klo
-                if (count_piece5(sq, (fo[k] >> 16) & rng, (second ? dbase2 : dbase1) + j0, pw_lim, wrep)) redo |= 1u << k;
+                const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
+                redo |= count_piece5(sq, (fo[k] >> 16) & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
             }
-            todo = todo && !now;
+            todo = todo & !now;
         }
         bool want_status = bad_extra;
         if (__ballot(redo != 0u)) {
@@ -616,15 +624,15 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                     const int32_t j0 = (int32_t)(p * 16u) - (int32_t)phi;
                     const bool second = j0 + (int32_t)phi >= qb1;
                     const int32_t sa = second ? a2 : a1, sb_ = second ? b2 : b1;
-                    careful(j0 < sa ? sa : j0, j0 + 16 < sb_ ? j0 + 16 : sb_, sa, second ? pos2 : ts.pos);
+                    careful(j0 < sa ? sa : j0, j0 + 16 < sb_ ? j0 + 16 : sb_, sa, second ? pos2 : tpos);
                 }
                 if ((redo >> F5_NP) & 1u) careful(a2, xbe - (int32_t)phi, a2, pos2);
             }
         }
         // ---- hand-over to the general pass: the block's segment of the list -----------------------------------------------
         {
-            const bool status_only = !general && counted && want_status;      // a base could not be counted: exact status wanted
-            const bool has = general || status_only;
+            const bool status_only = !general & counted & want_status;        // a base could not be counted: exact status wanted
+            const bool has = general | status_only;
             const unsigned long long m = __ballot(has);
             if (m) {
                 uint32_t base = 0;
@@ -654,31 +662,43 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             }
         }
     }
-    if (n_err) atomicAdd(&ctr[2], n_err);
+    if (n_err) atomicAdd(&ctr[2], (unsigned long long)n_err);
     if (tid == 0) gcnt[blockIdx.x] = s_gcur;
 }
 
-static inline FastGrid fast5_grid(int64_t n_reads, int n_cu) {
+struct Fast5Cfg { int waves, qrun; };
+// which build: by the mean padded read length of the batch (bases, a multiple of 8 per read)
+static inline Fast5Cfg fast5_cfg(int64_t n_reads, int64_t n_bases_padded, int window) {
+    const int64_t mean_pad = n_reads > 0 ? (n_bases_padded + n_reads - 1) / n_reads : 0;
+    if (mean_pad <= 152 || window != 4) return Fast5Cfg{8, 9728};          // (the other two are built for the default window only)
+    if (mean_pad <= 192) return Fast5Cfg{6, 13312};
+    return Fast5Cfg{4, 19456};
+}
+static inline FastGrid fast5_grid(int64_t n_reads, int n_cu, const Fast5Cfg &cf) {
     int64_t rpb = (n_reads + (int64_t)n_cu - 1) / (int64_t)n_cu;
     rpb = ((rpb + 63) / 64) * 64;
-    if (rpb < 2 * F5_WAVES * 64) rpb = 2 * F5_WAVES * 64;
+    if (rpb < 2 * cf.waves * 64) rpb = 2 * cf.waves * 64;
     return FastGrid{(n_reads + rpb - 1) / rpb, rpb};
 }
 
 static inline int fast5_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out, uint32_t *counts,
-                               const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, hipStream_t stream) {
-    const unsigned g = (unsigned)fg.grid, t = F5_WAVES * 64;
+                               const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, const Fast5Cfg &cf, hipStream_t stream) {
+    const unsigned g = (unsigned)fg.grid;
     const int rpb = (int)fg.rpb;
-    switch (P.window) {
-        case 1: k_fast5<1><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 2: k_fast5<2><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 3: k_fast5<3><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 4: k_fast5<4><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 5: k_fast5<5><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 6: k_fast5<6><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        case 7: k_fast5<7><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
-        default: k_fast5<8><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb); break;
+#define AMP_F5_GO(w, wv, qr, rp, pw) k_fast5<w, wv, qr, rp, pw><<<g, wv * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb)
+    if (cf.waves == 6) AMP_F5_GO(4, 6, 13312, 2, 512);
+    else if (cf.waves == 4) AMP_F5_GO(4, 4, 19456, 4, 512);
+    else switch (P.window) {
+        case 1: AMP_F5_GO(1, 8, 9728, 4, 256); break;
+        case 2: AMP_F5_GO(2, 8, 9728, 4, 256); break;
+        case 3: AMP_F5_GO(3, 8, 9728, 4, 256); break;
+        case 4: AMP_F5_GO(4, 8, 9728, 4, 256); break;
+        case 5: AMP_F5_GO(5, 8, 9728, 4, 256); break;
+        case 6: AMP_F5_GO(6, 8, 9728, 4, 256); break;
+        case 7: AMP_F5_GO(7, 8, 9728, 4, 256); break;
+        default: AMP_F5_GO(8, 8, 9728, 4, 256); break;
     }
+#undef AMP_F5_GO
     return (int)hipGetLastError();
 }
 

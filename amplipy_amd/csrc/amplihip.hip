@@ -1058,7 +1058,8 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const int kv = (c->kernel_variant >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : c->kernel_variant;
     const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
-    const FastGrid fg = fast_grid(n, c->n_cu);
+    const Fast5Cfg f5 = fast5_cfg(n, rd->n_bases_padded, c->window);
+    const FastGrid fg = kv == 5 ? fast5_grid(n, c->n_cu, f5) : fast_grid(n, c->n_cu);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without
@@ -1100,7 +1101,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        if ((kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream)
+        if ((kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, f5, c->stream)
                      : fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64)) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }

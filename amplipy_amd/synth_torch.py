@@ -34,10 +34,11 @@ class DeviceBatch:
     def rows(self, lo, hi):
         """Rows [lo, hi) as a batch that shares this one's CIGAR / base / quality arrays (offsets stay absolute:
         the kernels index those arrays through cig_off32 / seq_off8).  n_cig is the END offset of the last row, so
-        that an output CIGAR array of n_cig + 3 n words has room for the slots cig_off32[i] + 3 i."""
+        that an output CIGAR array of n_cig + 3 n words has room for the slots cig_off32[i] + 3 i; n_bases_padded is the
+        rows' own (the library picks the fast kernel's tile geometry by the mean padded row length)."""
         return DeviceBatch(hi - lo, self.pos[lo:hi], self.flag[lo:hi], self.tlen[lo:hi], self.lseq[lo:hi],
                            self.cig_off32[lo:hi + 1], self.cig, self.seq_off8[lo:hi + 1], self.seq, self.qual,
-                           int(self.cig_off32[hi].item()), self.n_bases_padded)
+                           int(self.cig_off32[hi].item()), int((self.seq_off8[hi] - self.seq_off8[lo]).item()) * 8)
 
     def to_host(self, lo=0, hi=None):
         """Rows [lo, hi) as a host ReadBatch (for the CPU baseline / parity check)."""

@@ -134,7 +134,8 @@ typedef struct amp_dev_reads {
     const uint8_t *seq;
     const uint8_t *qual;
     int64_t n_cig;             /* cig_off32[n], known to the host */
-    int64_t n_bases_padded;    /* seq_off8[n] * 8 */
+    int64_t n_bases_padded;    /* padded bases of the rows: (seq_off8[n] - seq_off8[0]) * 8; only its mean per row is used (it picks
+                                * the tile geometry of the fast kernel: a value that is too large costs speed, not correctness) */
 } amp_dev_reads;
 
 /* ---- library ------------------------------------------------------------------------ */

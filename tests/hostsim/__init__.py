@@ -14,8 +14,8 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libhostsim.so")
         src = os.path.join(_HERE, "hostsim.hip")
-        hdr = os.path.join(_HERE, "..", "..", "amplipy_amd", "csrc", "amp_read.hpp")
-        if not os.path.isfile(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        hdrs = [os.path.join(_HERE, "..", "..", "amplipy_amd", "csrc", h) for h in ("amp_read.hpp", "amp_bf.hpp")]
+        if not os.path.isfile(so) or os.path.getmtime(so) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
             subprocess.check_call(["hipcc", "-O1", "-fPIC", "-shared", "--offload-arch=gfx950", "-o", so, src])
         _LIB = C.CDLL(so)
         _LIB.sim_process_range.restype = C.c_int
@@ -35,4 +35,13 @@ def cig2_fuzz(seed, iters):
     L.sim_cig2_fuzz.restype = C.c_long
     np_, nc = C.c_long(0), C.c_long(0)
     bad = L.sim_cig2_fuzz(C.c_uint64(seed), C.c_long(iters), C.byref(np_), C.byref(nc))
+    return int(bad), int(np_.value), int(nc.value)
+
+
+def bf_fuzz(seed, iters):
+    """(mismatches, punted, compared) of the branch-free closed forms (amp_bf.hpp) against the branchy ones."""
+    L = lib()
+    L.sim_bf_fuzz.restype = C.c_long
+    np_, nc = C.c_long(0), C.c_long(0)
+    bad = L.sim_bf_fuzz(C.c_uint64(seed), C.c_long(iters), C.byref(np_), C.byref(nc))
     return int(bad), int(np_.value), int(nc.value)

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../amplipy_amd/csrc/amp_read.hpp"
+#include "../../amplipy_amd/csrc/amp_bf.hpp"
 
 using namespace amp;
 
@@ -184,6 +185,72 @@ extern "C" long sim_cig2_fuzz(uint64_t seed, long iters, long *n_punt, long *n_c
                 fprintf(stderr, " L %d R %d\n", mx[rs], mn[re1 < G && re1 >= 0 ? re1 : 0]);
             }
             ++bad;
+        }
+    }
+    return bad;
+}
+
+
+// ---- fuzz of the branch-free closed forms (amp_bf.hpp) against the branchy ones (Cig2, themselves fuzzed against the
+// generic code above): same inputs, same primer tables, every scan outcome i in [0, qlen] ------------------------------
+extern "C" long sim_bf_fuzz(uint64_t seed, long iters, long *n_punt, long *n_cmp) {
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 777;
+    long bad = 0; *n_punt = 0; *n_cmp = 0;
+    for (long it = 0; it < iters; ++it) {
+        const int kind = rin(0, 2);
+        const int32_t m1 = rin(1, 60), k = kind ? rin(1, 20) : 0, m2 = kind ? rin(1, 60) : 0;
+        const uint32_t op = (rnd() % 8 == 0) ? OP_EQ : OP_M;
+        const int32_t sa = rnd() % 3 == 0 ? rin(1, 30) : 0, sc = rnd() % 3 == 0 ? rin(1, 30) : 0;
+        uint32_t in[5] = {0, 0, 0, 0, 0}; int n = 0;
+        if (sa) in[n++] = ((uint32_t)sa << 4) | OP_S;
+        in[n++] = ((uint32_t)m1 << 4) | op;
+        if (kind) { in[n++] = ((uint32_t)k << 4) | (kind == 1 ? OP_I : OP_D); in[n++] = ((uint32_t)m2 << 4) | op; }
+        if (sc) in[n++] = ((uint32_t)sc << 4) | OP_S;
+        // words past the read's own repeat its first (as the kernel loads them); sometimes a broken CIGAR
+        uint32_t w[5];
+        for (int j = 0; j < 5; ++j) w[j] = j < n ? in[j] : in[0];
+        if (rnd() % 16 == 0) w[rnd() % n] ^= (1u << (rnd() % 8));
+        int32_t lseq = sa + m1 + (kind == 1 ? k : 0) + m2 + sc;
+        if (rnd() % 32 == 0) lseq += rin(-2, 2);
+        const int32_t pos = rin(0, 420);
+        const uint32_t flag = (rnd() & 1u) | ((rnd() & 1u) << 4);
+        const bool isize = rnd() & 1u;
+        // table entries anywhere around the read, or None
+        int32_t L = rnd() % 3 == 0 ? -1 : pos + rin(-40, 160), R = rnd() % 3 == 0 ? -1 : pos + rin(-40, 200);
+        if (kind && rnd() % 4 == 0) {       // aimed at the indel: a start clip that ends in or next to it, an end clip that reaches it from the other side
+            L = pos + m1 + rin(-2, (kind == 2 ? k : 0) + 2) - 1;
+            if (rnd() & 1u) R = pos + m1 + (kind == 2 ? k : 0) + rin(-3, 3);
+        }
+        Cig2 s2;
+        const bool ok2 = cig2_from_words5(n, w, lseq, s2) && !((s2.kind == 1 && s2.k > 8) || (s2.kind == 2 && s2.k > 16));
+        bool ok3;
+        Bf s3 = bf_from_words5(n, w[0], w[1], w[2], w[3], w[4], lseq, 8, 16, ok3);
+        if (ok2 != ok3) { ++bad; continue; }
+        if (!ok2) continue;
+        TrimState t2{pos, n, 0u, 0};
+        cig2_trim_primers_isize(t2, flag, isize, lseq, s2, L < 0 ? -1 : L, R < 0 ? -1 : R);
+        int32_t p3 = pos; uint32_t f3 = 0u;
+        s3 = bf_trim_primers(s3, p3, f3, flag, isize, lseq, L < 0 ? -1 : L, R < 0 ? -1 : R);
+        if ((s2.punt ? 1u : 0u) != (s3.punt ? 1u : 0u)) { ++bad; continue; }
+        if (s2.punt) { ++*n_punt; continue; }
+        auto same_shape = [&](const Cig2 &x, const Bf &y) {
+            return x.a == y.a && x.m1 == y.m1 && x.k == y.k && x.m2 == y.m2 && x.c == y.c && x.kind == y.kind && x.op == y.op;
+        };
+        if (!same_shape(s2, s3) || t2.pos != p3 || t2.flags != f3) { ++bad; continue; }
+        int32_t lo2, ql2, lo3, ql3;
+        cig2_quality_window(s2, lseq, lo2, ql2);
+        bf_quality_window(s3, lseq, lo3, ql3);
+        if (lo2 != lo3 || ql2 != ql3) { ++bad; continue; }
+        const bool rev = (flag & 0x10u) != 0;
+        for (int32_t i = 0; i <= ql2; i += (ql2 > 24 && i > 4 && i < ql2 - 4) ? rin(1, 5) : 1) {
+            Cig2 a2 = s2; TrimState u2 = t2;
+            cig2_trim_quality(u2, rev, i, ql2, a2);
+            uint32_t g3 = f3;
+            const Bf a3 = bf_trim_quality(s3, p3, g3, rev, i, ql3);
+            ++*n_cmp;
+            if ((a2.punt ? 1u : 0u) != (a3.punt ? 1u : 0u)) { ++bad; continue; }
+            if (a2.punt) continue;
+            if (!same_shape(a2, a3) || u2.flags != g3 || a2.ref_len() != a3.ref_len()) ++bad;
         }
     }
     return bad;

@@ -116,3 +116,14 @@ def test_two_segment_closed_forms():
         bad, punted, compared = hostsim.cig2_fuzz(seed, 200000)
         assert bad == 0, (seed, bad)
         assert compared > 190000 and punted < 5000
+
+
+def test_branch_free_closed_forms():
+    """amp_bf.hpp (the closed forms of Cig2 written as arithmetic and selects: what the fast kernel, variant 5, runs) against
+    the branchy forms of the test above on random shapes, table entries aimed at and around the indel, both strands and
+    EVERY outcome of the window scan: parse result, trimmed shape, position and flags must be identical."""
+    from tests import hostsim
+    for seed in (21, 22, 23):
+        bad, punted, compared = hostsim.bf_fuzz(seed, 150000)
+        assert bad == 0, (seed, bad)
+        assert compared > 1000000

@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(base, "kt", "*kernel_stats.csv")):
         if any(k in r["Name"] for k in ("amp::", "k_def", "k_call", "k_event")):
             print("%-42s calls %3s avg %9.1f us" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(base, "pmc_*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(base, "pmc_*", "*counter_collection.csv")) + glob.glob(os.path.join(base, "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
         if any(k in n for k in ("amp::", "k_def")):
