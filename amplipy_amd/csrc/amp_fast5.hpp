@@ -313,10 +313,12 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         sh0 = shape_of(h0, c, g0.fastq);
     }
     Tabs tb0 = load_tabs(h0, sh0);
+    uint32_t pfA = 0u, pfB = 0u;                   // (L2 prefetch of the next tile's bases: see below)
     while (tk0 < n_tb) {
         // ---- everything issued a phase or more ago has arrived: this tile's qualities and table entries, the next tile's
         // CIGAR words, the header of the tile behind it -------------------------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : : "v"(pfA), "v"(pfB));
         const HdrP h = h0;
         const Geo g = g0;
         const Shape shp = sh0;
@@ -342,28 +344,6 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             ++pw_tiles;
         }
         pw_lim = (int64_t)G - pw_base >= (int64_t)F5_PW ? (uint32_t)F5_PW : (uint32_t)(G > (uint32_t)pw_base ? G - (uint32_t)pw_base : 0u);
-        // ---- pass over the qualities: slot k of the lane is piece (k + rot) mod np of its read; per piece 16 failing-window
-        // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality) and 16
-        // good-quality bits, kept as fo[k] = fail | ok << 16 ------------------------------------------------------------------
-        const uint32_t rot = (uint32_t)lane % np;
-        const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
-        const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
-        const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
-        uint32_t fo[F5_NP];
-#pragma unroll
-        for (int k = 0; k < F5_NP; ++k) {
-            fo[k] = 0u;
-            if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;                                 // (uniform)
-            uint32_t p = (uint32_t)k + rot;
-            p = p >= np ? p - np : p;
-            p = (uint32_t)k < np ? p : np - 1u;
-            const lds_u8 *src = qst + lrow + (int32_t)(p * 16u);
-            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
-            const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
-            const uint32_t fail = P.do_trim ? piece_fail_bits<W>(q, make_uint2(c.x, c.y), thr) : 0u;
-            fo[k] = fail | (ok_bits16(q, mqb) << 16);
-        }
-        const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
         // ---- primer clips in closed form (A:450-558), branch-free (amp_bf.hpp) --------------------------------------
         const bool shaped = shp.ok;
         const bool in_ref = ((uint32_t)pos < G) & ((uint32_t)(pos + shp.refspan - 1) < G);      // A:450-451
@@ -385,22 +365,37 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         bf_quality_window(s, (int32_t)lseq, lo, qlen);
         lo = scan ? lo + (int32_t)phi : 0; qlen = scan ? qlen : 0;
         const int32_t hi = lo + qlen;
-        // ---- first failing window start (forward) / last failing window end (reverse) inside [lo, hi) ---------------
+        // ---- pass over the qualities: slot k of the lane is piece (k + rot) mod np of its read.  Per piece: 16 failing-window
+        // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality), of which the
+        // first / last inside [lo, hi - W] give the first failing window start (forward) / last failing window end
+        // (reverse); and 16 good-quality bits, kept as ok[k] for the counting phase ------------------------------------------
+        const uint32_t rot = (uint32_t)lane % np;
+        const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
+        const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
+        const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
+        uint32_t fo[F5_NP];
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
-        if (P.do_trim && !(AMP_F5_ABL & 8)) {
 #pragma unroll
-            for (int k = 0; k < F5_NP; ++k) {
-                if (!((live >> k) & 1u)) continue;
-                uint32_t p = (uint32_t)k + rot;
-                p = p >= np ? p - np : p;
-                p = (uint32_t)k < np ? p : np;
+        for (int k = 0; k < F5_NP; ++k) {
+            fo[k] = 0u;
+            if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;             // (uniform)
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
+            const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
+            p = (uint32_t)k < np ? p : np;
+            const lds_u8 *src = qst + lrow + (int32_t)(pa * 16u);
+            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
+            const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
+            fo[k] = ok_bits16(q, mqb);
+            if (P.do_trim) {
                 const int32_t j0 = (int32_t)(p * 16u);
-                const uint32_t fail = (fo[k] & 0xFFFFu) & range_bits16(lo - j0, hi - W - j0 + 1);      // window starts j0+b must lie in [lo, hi - W]
+                const uint32_t fail = piece_fail_bits<W>(q, make_uint2(c.x, c.y), thr) & range_bits16(lo - j0, hi - W - j0 + 1);      // window starts j0+b must lie in [lo, hi - W]
                 const int32_t f1 = j0 + (__builtin_ffs((int)fail) - 1), e1 = j0 + (31 - __builtin_clz(fail)) + W;
                 ffmin = ((fail != 0u) & (f1 < ffmin)) ? f1 : ffmin;
                 lemax = ((fail != 0u) & (e1 > lemax)) ? e1 : lemax;
             }
         }
+        const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
         // ---- quality clip (A:589-686) --------------------------------------------------------------------------------
         int32_t iq = rev ? 0 : qlen;
         {
@@ -475,6 +470,16 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         tb0 = load_tabs(h1, sh1);
         cN = load_cig(h2);
         hR = load_hdr(i3);
+        {
+            // the next tile's packed bases are pulled into L2 now (one dword of every 128-byte line; plain loads whose values
+            // are only "used" behind the wait at the top of the loop): their LDS-DMA can only be issued when this tile's bases
+            // have been counted, a third of a tile before they are needed
+            const uint32_t nb = g1.Tq >> 1;
+            const uint32_t off = (uint32_t)lane * 128u;
+            const uint8_t *sb = rd.seq + (int64_t)g1.m0 * 4;
+            pfA = *(const uint32_t *)(sb + (off < nb ? off : 0u));
+            if (F5_QRUN / 2 > 8192) pfB = *(const uint32_t *)(sb + (off + 8192u < nb ? off + 8192u : 0u));
+        }
         // pad nibbles of the staged rows (a row is padded to 8 bases) become a valid code: the test for codes outside
         // A C G T looks at whole pieces
         {
@@ -594,7 +599,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 const lds_u8 *sp = lsrow + pa * 8u;
                 const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
                 const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
-                redo |= count_piece5(sq, (fo[k] >> 16) & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
+                redo |= count_piece5(sq, fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
             }
             todo = todo & !now;
         }

@@ -83,7 +83,7 @@ struct amp_ctx {
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
-    int kernel_variant = 4;       // 5 = fast kernel (second generation) + general pass, 4 = its first generation, 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
+    int kernel_variant = 0;       // 0 = by the batch (4 for reads of up to 152 padded bases on average, else 5), 5 = fast kernel (second generation) + general pass, 4 = its first generation, 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
                                   // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
     uint32_t phases = 0xFFu;       // always 0xFF in the shipped library; -DAMP_DEV builds can mask phases of the tile kernel (AMPLIHIP_PHASES)
@@ -924,7 +924,7 @@ int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(AMP_EHIP);
 #ifdef AMP_DEV   // development builds only (tools/profile_phases.sh): the shipped library reads no debug switches
     const char *v = getenv("AMPLIHIP_KERNEL");
-    if (v && v[0] >= '1' && v[0] <= '5') c->kernel_variant = v[0] - '0';
+    if (v && v[0] >= '0' && v[0] <= '5') c->kernel_variant = v[0] - '0';
     v = getenv("AMPLIHIP_PHASES");
     if (v) c->phases = (uint32_t)strtoul(v, nullptr, 0);
 #endif
@@ -997,7 +997,7 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
 }
 
 int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 / 5 = fast kernel (first / second generation) + general pass
-    if (!c || variant < 1 || variant > 5) return AMP_EINVAL;
+    if (!c || variant < 0 || variant > 5) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -1055,10 +1055,14 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     if (n > (int64_t)DEFER_INDEX_MASK) return AMP_EINVAL;
     // windows wider than a chunk take the serial scan of the general kernel, and the fast kernel's byte-parallel
     // quality test is written for min_quality <= 128: no fast pass for such runs
-    const int kv = (c->kernel_variant >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : c->kernel_variant;
+    // the fast kernel by the batch: its first generation (amp_fast.hpp) keeps a read in registers and is the quicker one for
+    // reads of up to 152 bases; the second (amp_fast5.hpp) consumes reads from LDS and takes them up to 304 bases (200 and
+    // 250 bp runs: 1.5 x and 1.3 x the first generation, which hands such reads to the general pass)
+    const Fast5Cfg f5 = fast5_cfg(n, rd->n_bases_padded, c->window);
+    const int kv0 = c->kernel_variant == 0 ? (f5.waves == 8 ? 4 : 5) : c->kernel_variant;
+    const int kv = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
     const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
-    const Fast5Cfg f5 = fast5_cfg(n, rd->n_bases_padded, c->window);
     const FastGrid fg = kv == 5 ? fast5_grid(n, c->n_cu, f5) : fast_grid(n, c->n_cu);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]

@@ -229,10 +229,12 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * events of a batch plus 64 slots per wave of the fast kernel (8 per CU) and of the many-op kernel (24 per CU): waves
  * reserve list slots 64 at a time and leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 4 (default) = the fast kernel (closed-form trim + pileup of reads with one match op or one insertion / deletion, every byte
- * loaded once) followed by the general pass over the reads it hands over; 2 = the fused tile kernel over every read; 1 =
- * one-lane-per-read kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks
- * (all four give identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
+/* 0 (default) = chosen per batch between 4 and 5 by its mean padded read length.  4 = the fast kernel (closed-form trim +
+ * pileup of reads with one match op or one insertion / deletion of up to 152 bases, every byte loaded once) followed by the
+ * general pass over the reads it hands over; 5 = its second generation (reads consumed from LDS staging buffers,
+ * branch-free closed forms, reads of up to 304 bases); 2 = the fused tile kernel over every read; 1 = one-lane-per-read
+ * kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks (all give
+ * identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
 
 /* ---- calling: alleles_from_counts (AmpliPy.py:756-771) + the loop AmpliPy.py:917-952 --------

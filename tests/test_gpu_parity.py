@@ -12,7 +12,7 @@ from tests.gpu_util import GpuRunner, assert_same
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[4, 2, 1, 3], ids=["fast_kernel", "tile_kernel", "lane_kernel", "split_pipeline"])
+@pytest.fixture(scope="module", params=[4, 5, 2, 1, 3], ids=["fast_kernel", "fast_kernel_v5", "tile_kernel", "lane_kernel", "split_pipeline"])
 def runner(request):
     r = GpuRunner(variant=request.param)
     yield r
@@ -130,7 +130,7 @@ def test_replication_property_full_depth(runner, scheme):
     a = oracle.process(base, g.size, mn, mx, mpl)
     e = runner.engine(g.size)
     e.reset(); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
-    k = 100 if runner.variant == 4 else 10
+    k = 100 if runner.variant in (4, 5) else 10
     for rep in range(k):
         e.process(base, read_base=0, want_trim=False)
     assert np.array_equal(e.counts(), a.counts * np.uint32(k))
@@ -412,6 +412,67 @@ def test_function_level_seams_replay_the_named_cases():
     assert n_checked >= 30
     tot, alleles = compat.alleles_from_counts({"A": 3, "C": 0, "AT": 3, "-": 1, "T": 3})
     assert tot == 10 and [a[2] for a in alleles] == ["T", "AT", "A", "-"] and alleles[0][1] == 0.3
+
+
+@pytest.mark.parametrize("seed,mq,w,off,lmin,lmax", [(61, 20, 4, 0, 160, 304), (62, 20, 4, 1, 100, 200), (63, 10, 4, 0, 240, 304), (64, 30, 3, 2, 60, 304), (65, 20, 4, 0, 250, 250)])
+def test_reads_of_up_to_304_bases_with_one_indel(runner, seed, mq, w, off, lmin, lmax):
+    """The second-generation fast kernel (amp_fast5.hpp, branch-free closed forms of amp_bf.hpp) takes reads of up to 304
+    bases and runs in three builds chosen by the batch's mean padded read length (runs of 9.7 / 13.3 / 19.5 KB per tile,
+    packed windows of 256 / 512 positions): reads of the given length range with one match op or two around one insertion /
+    deletion, soft clips, dense primer tables, low-quality ends, N calls; reads longer than the fast path takes mixed in.
+    Trim results, count table and insertion events against the oracle (every kernel variant must agree)."""
+    from amplipy_amd.segment import Segment
+    rng = np.random.default_rng(seed)
+    G = 9000
+    primers = sorted((int(a), int(a) + int(rng.integers(18, 32))) for a in rng.integers(0, G - 40, 80))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, off)
+    segs = []
+    starts = np.sort(np.concatenate([rng.integers(0, G - 400, 40), [0, 1, G - 330]]))
+    for s0 in starts:
+        for _ in range(int(rng.integers(40, 160))):
+            L = int(rng.integers(lmin, lmax + 1)) if rng.random() < 0.97 else int(rng.integers(305, 340))
+            kind = int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+            sa = int(rng.integers(1, 30)) if rng.random() < 0.2 else 0
+            sc = int(rng.integers(1, 30)) if rng.random() < 0.2 else 0
+            k = int(rng.integers(1, 9)) if kind else 0
+            body = L - sa - sc - (k if kind == 1 else 0)
+            if body < 4:
+                continue
+            m1 = int(rng.integers(1, body - 1)) if kind else body
+            m2 = body - m1 if kind else 0
+            cig = ([(4, sa)] if sa else []) + [(0, m1)] + ([(kind, k), (0, m2)] if kind else []) + ([(4, sc)] if sc else [])
+            span = m1 + m2 + (k if kind == 2 else 0)
+            pos = int(min(max(s0 + rng.integers(-3, 4), 0), G - span - 1))
+            q = rng.choice([37, 25, 11, 2], L, p=[0.7, 0.15, 0.1, 0.05]).astype(np.int64)
+            t = int(rng.integers(0, 40))
+            if rng.random() < 0.3:
+                q[:t] = 2
+            elif rng.random() < 0.4:
+                q[L - t:] = 2
+            seq = "".join(rng.choice(list("ACGTN"), L, p=[0.2475, 0.2475, 0.2475, 0.2475, 0.01]))
+            flag = int(rng.choice([0, 16, 99, 147, 83, 163]))
+            segs.append(Segment(flag=flag, reference_start=pos, cigar=cig, template_length=int(rng.choice([0, 400, -400, 90])),
+                                query_sequence=seq, query_qualities=q.tolist()))
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    a = oracle.process(b, G, mn, mx, mpl, mq, w)
+    d = runner.process(b, G, mn, mx, mpl, mq, w)
+    assert_same(a, d, b, check_counts=False)
+    ok = np.nonzero(a.trim.status == 0)[0]
+    assert ok.size > 0.9 * b.n
+    good = ReadBatch.from_segments([segs[i] for i in ok])
+    for do_trim in (True, False):
+        a = oracle.process(good, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        keep = np.nonzero(a.trim.status == 0)[0]
+        good2 = good if keep.size == good.n else ReadBatch.from_segments([segs[ok[i]] for i in keep])
+        a = oracle.process(good2, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        d = runner.process(good2, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        assert_same(a, d, good2)
+        assert a.events.size > 50
+    if runner.variant == 5 and w == 4:
+        # the fast path really took them: what is left for the general pass is the reads of more than 304 bases and little else
+        left = int(runner.engine(G).debug_counters()[7])
+        assert left < 0.1 * good2.n, (left, good2.n)
 
 
 @pytest.mark.parametrize("seed,mq,w,off", [(41, 20, 4, 0), (42, 10, 1, 2), (43, 30, 8, 1), (44, 0, 3, 0), (45, 25, 6, 3), (46, 20, 2, 0)])

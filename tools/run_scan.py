@@ -8,11 +8,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--depth", type=int, default=10000); ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--variant", type=int, default=4); ap.add_argument("--check", action="store_true")
 ap.add_argument("--indel-frac", type=float, default=0.10)
+ap.add_argument("--read-len", type=int, default=150)
 ap.add_argument("--same-rows", action="store_true", help="every read points at the bytes of read 0 (timing experiment: no HBM traffic for bases / qualities; results are wrong on purpose)")
 a = ap.parse_args()
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme(); G = g.size
-n = synth.reads_for_depth(a.depth)
-b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0", indel_frac=a.indel_frac); torch.cuda.synchronize()
+n = synth.reads_for_depth(a.depth, a.read_len)
+b = synth_torch.make_amplicon_batch_device(g, amps, n, 1000, "cuda:0", read_len=a.read_len, indel_frac=a.indel_frac); torch.cuda.synchronize()
 if a.same_rows:
     b.seq_off8.zero_()
 mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
