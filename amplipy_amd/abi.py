@@ -22,6 +22,8 @@ READ_STATUS_NAMES = {0: "OK", 1: "INDEX_REF", 2: "INDEX_PAIRS", 3: "INDEX_QUERY"
 TRIM_PRIMER_START, TRIM_PRIMER_END, TRIM_QUALITY = 1, 2, 4
 
 INS_EVENT_DTYPE = np.dtype([("ref_pos", "<i4"), ("read", "<u4"), ("q_from", "<i4"), ("q_to", "<i4")])
+# amp_ins_run: one record per (ref_pos, allele) of amp_aggregate_ins_events
+INS_RUN_DTYPE = np.dtype([("ref_pos", "<i4"), ("read", "<u4"), ("q_from", "<i4"), ("q_to", "<i4"), ("count", "<u4"), ("reserved", "<u4")])
 
 
 class AmpInsEvent(C.Structure):

@@ -169,16 +169,19 @@ def _raise_for_status(status):
     raise exc("read rejected by the engine: %s (the reference raises %s here)" % (abi.READ_STATUS_NAMES[int(status)], exc.__name__))
 
 
-def _store_events(eng, ins_store, ev, read_base):
-    """A batch's insertion events with their allele text (A:736-738) into the store.  The text is gathered on the device, from
-    the copy of the batch that eng.process() left there: on the host the gather was half a second per million
-    events (a run of Nanopore-like reads records eight events a read)."""
-    if ev.size == 0:
+def _store_events(eng, ins_store, read_base):
+    """A batch's insertion alleles (A:730-748) into the store: the device sorts the batch's events by (position, allele) and
+    run-length encodes them (amp_aggregate_ins_events), the text of one representative per allele is gathered on
+    the device from the copy of the batch that eng.process() left there (A:736-738), and the event list starts over."""
+    runs = eng.aggregate_events(read_base=read_base, drain=True)
+    if runs.size == 0:
         return
-    rows = ev.copy()
-    rows["read"] = (ev["read"].astype(np.int64) - (read_base & 0xFFFFFFFF)) & 0xFFFFFFFF     # read ids are 32-bit, relative to read_base modulo 2^32
+    rows = np.zeros(runs.size, abi.INS_EVENT_DTYPE)
+    for f in ("ref_pos", "q_from", "q_to"):
+        rows[f] = runs[f]
+    rows["read"] = (runs["read"].astype(np.int64) - (read_base & 0xFFFFFFFF)) & 0xFFFFFFFF     # read ids are 32-bit, relative to read_base modulo 2^32
     length, blob = eng.event_text(rows, 0)
-    ins_store.add_text(ev["ref_pos"], length, blob)
+    ins_store.add_text(runs["ref_pos"], length, blob, runs["count"])
 
 
 def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trimmed_reads_fn=None, variants_fn=None,
@@ -286,8 +289,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         if do_count:
             # this batch's events only: the list is drained batch by batch (read ids are 32-bit and relative to
             # read_base modulo 2^32, which a batch never spans)
-            ev = eng.drain_events()
-            _store_events(eng, ins_store, ev, read_base)
+            _store_events(eng, ins_store, read_base)
         read_base += batch.n
         del pending[:]
 
@@ -339,8 +341,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                 if len(bad):
                     _raise_for_status(res.status[bad[0]])
                 if do_count:
-                    ev = eng.drain_events()
-                    _store_events(eng, ins_store, ev, read_base)
+                    _store_events(eng, ins_store, read_base)
                 read_base += batch.n
         finally:
             if wq is not None:
@@ -379,10 +380,10 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             parallel.allreduce_table(dist, table)      # the ONE collective of the run: every rank now holds the job's table
 
         def ins_tallies(positions):
-            pairs = ins_store.pairs(positions)
+            triples = ins_store.counted_pairs(positions)
             if dist is not None:                       # all ranks flag the same positions (same table): symmetric exchange
-                pairs = parallel.allgather_relevant_events(dist, world, pairs)
-            return calling.tallies_from_events(pairs, positions)
+                triples = parallel.allgather_relevant_events(dist, world, triples)
+            return calling.tallies_from_runs(triples, positions)
         res = calling.call(eng, ref_seq, cp, ins_tallies)
         if rank != 0:
             run_variants = run_consensus = False       # rank 0 writes the outputs

@@ -7,11 +7,17 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "amplihip.hip")
-DEPS = [SRC, os.path.join(_HERE, "..", "include", "amplihip.h")] + sorted(
-    os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".hpp"))
+CSRC = os.path.join(_HERE, "csrc")
+# translation units of libamplihip.so: the kernels + C ABI, and the insertion-event aggregation (its sort headers triple the
+# compile time of whatever includes them, so it is built -- and cached -- on its own)
+UNITS = ["amplihip.hip", "amp_ins.hip"]
+SRC = os.path.join(CSRC, "amplihip.hip")
+HEADERS = [os.path.join(_HERE, "..", "include", "amplihip.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+UNIT_DEPS = {"amplihip.hip": HEADERS, "amp_ins.hip": [os.path.join(_HERE, "..", "include", "amplihip.h"), os.path.join(CSRC, "amp_ins.hpp")]}
+DEPS = [os.path.join(CSRC, u) for u in UNITS] + HEADERS
 OUT = os.path.join(_HERE, "libamplihip.so")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+OBJ_DIR = os.path.join(_HERE, "build")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 
 
 def needs_build():
@@ -25,7 +31,19 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", OUT, SRC, "-ldl"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for u in UNITS:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJ_DIR, u.replace(".hip", ".o"))
+        stale = force or extra_flags or not os.path.isfile(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + UNIT_DEPS[u])
+        if stale:
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

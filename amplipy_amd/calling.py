@@ -238,3 +238,13 @@ def tallies_from_events(events_with_strings, positions):
         if pos in positions:
             out[pos][s] += 1
     return out
+
+
+def tallies_from_runs(runs_with_strings, positions):
+    """{pos: {string: count}} from [(ref_pos, string, count)] (the runs of Engine.aggregate_events with their text)
+    restricted to ``positions``; rows of one allele are summed."""
+    out = defaultdict(lambda: defaultdict(int))
+    for pos, s, c in runs_with_strings:
+        if pos in positions:
+            out[pos][s] += c
+    return out

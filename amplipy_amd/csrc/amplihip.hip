@@ -22,6 +22,7 @@
 #include "amp_fast.hpp"
 #include "amp_fast5.hpp"
 #include "amp_wave.hpp"
+#include "amp_ins.hpp"
 
 using namespace amp;
 
@@ -75,6 +76,7 @@ struct amp_ctx {
     DBuf o_pos, o_ncig, o_cig, o_reflen, o_flags, o_status;
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
+    DBuf agg_buf;                  // amp_aggregate_ins_events: run records + the sort's scratch
     void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
     bool call_pending = false;     // amp_call_compact_begin has enqueued the calling kernels; amp_call_compact_view picks them up
     amp_call_params call_pending_params{};
@@ -944,7 +946,7 @@ void amp_ctx_destroy(amp_ctx *c) {
     if (c->d_ref) (void)hipFree(c->d_ref);
     DBuf *bufs[] = {&c->events, &c->s_pos, &c->s_flag, &c->s_tlen, &c->s_lseq, &c->s_cigoff, &c->s_cig, &c->s_seqoff,
                     &c->s_seq, &c->s_qual, &c->o_pos, &c->o_ncig, &c->o_cig, &c->o_reflen, &c->o_flags, &c->o_status,
-                    &c->scratch, &c->call_buf};
+                    &c->scratch, &c->call_buf, &c->agg_buf};
     for (DBuf *b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1287,6 +1289,41 @@ int amp_drain_ins_events(amp_ctx *c, int64_t *n, amp_ins_event *buf, int64_t cap
     if (rc != AMP_OK || !buf) return rc;
     Guard g(c);
     HIPCHK(c, hipMemsetAsync(&c->d_ctr[16], 0, EV_SHARDS * sizeof(unsigned long long), c->stream));
+    return AMP_OK;
+}
+
+int amp_aggregate_ins_events(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base, int drain, int64_t *n_runs, amp_ins_run *buf, int64_t cap) {
+    if (!c || !n_runs) return AMP_EINVAL;
+    Guard g(c);
+    unsigned long long h[EV_SHARDS];
+    HIPCHK(c, hipMemcpyAsync(h, &c->d_ctr[16], sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t total = 0;
+    for (int s = 0; s < EV_SHARDS; ++s) { if ((int64_t)h[s] > c->ev_cap) return AMP_EOVERFLOW; total += (int64_t)h[s]; }
+    *n_runs = total;
+    if (!buf) return AMP_OK;
+    if (total > cap) return AMP_EOVERFLOW;
+    amp_dev_reads staged;
+    if (!rd) {           // the batch of the last amp_process_batch call: its device copy is still in the ctx's staging buffers
+        if (c->staged_n < 0) return AMP_ESTATE;
+        staged = amp_dev_reads{c->staged_n, c->s_pos.as<int32_t>(), c->s_flag.as<uint16_t>(), c->s_tlen.as<int32_t>(), c->s_lseq.as<uint32_t>(),
+                               c->s_cigoff.as<uint32_t>(), c->s_cig.as<uint32_t>(), c->s_seqoff.as<uint32_t>(), c->s_seq.as<uint8_t>(),
+                               c->s_qual.as<uint8_t>(), c->staged_ncig, c->staged_nbases};
+        rd = &staged;
+    }
+    int64_t n_ev = 0, nr = 0;
+    if (total) {
+        const size_t sb = amp::ins_scratch_bytes(total), rb = (((size_t)total * sizeof(amp_ins_run)) + 255) & ~(size_t)255;
+        HIPCHK(c, c->agg_buf.ensure(sb + rb));
+        amp_ins_run *d_runs = (amp_ins_run *)c->agg_buf.p;
+        const int rc = amp::ins_aggregate(c->stream, *rd, read_base, c->events.as<amp_ins_event>(), (long long)c->ev_cap, h,
+                                          (uint8_t *)c->agg_buf.p + rb, d_runs, &n_ev, &nr);
+        if (rc != 0) { snprintf(c->err, sizeof(c->err), "insertion-event aggregation failed: %d", rc); return AMP_EHIP; }
+        if (nr) HIPCHK(c, hipMemcpyAsync(buf, d_runs, (size_t)nr * sizeof(amp_ins_run), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *n_runs = nr;
+    if (drain) HIPCHK(c, hipMemsetAsync(&c->d_ctr[16], 0, EV_SHARDS * sizeof(unsigned long long), c->stream));
     return AMP_OK;
 }
 

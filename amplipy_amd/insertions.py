@@ -40,7 +40,7 @@ class EventStore:
     the positions calling asks about (AmpliPy.py:745-748 keys, restricted to where they can matter)."""
 
     def __init__(self):
-        self._pos = []; self._len = []; self._blob = []
+        self._pos = []; self._len = []; self._blob = []; self._cnt = []
 
     def add(self, batch, events, read_base=0):
         if events.size == 0:
@@ -52,28 +52,34 @@ class EventStore:
         first = np.cumsum(length) - length                       # offset of each event in the blob
         b = np.repeat(start - first, length) + np.arange(total, dtype=np.int64)     # base index of every blob byte
         nib = (batch.seq[b >> 1] >> ((1 - (b & 1)) * 4).astype(np.uint8)) & 15
-        self._pos.append(events["ref_pos"].astype(np.int64)); self._len.append(length); self._blob.append(_NT16[nib])
+        self._pos.append(events["ref_pos"].astype(np.int64)); self._len.append(length); self._blob.append(_NT16[nib]); self._cnt.append(np.ones(length.size, np.int64))
 
-    def add_text(self, ref_pos, length, blob):
-        """The same from allele text gathered elsewhere (Engine.event_text: on the device, from the batch it just processed)."""
+    def add_text(self, ref_pos, length, blob, count=None):
+        """The same from allele text gathered elsewhere (Engine.event_text: on the device, from the batch it just processed);
+        ``count`` = events per row when the rows are the runs of Engine.aggregate_events (one row per allele), else one each."""
         if len(ref_pos):
             self._pos.append(np.asarray(ref_pos, np.int64)); self._len.append(np.asarray(length, np.int64)); self._blob.append(np.asarray(blob, np.uint8))
+            self._cnt.append(np.ones(len(ref_pos), np.int64) if count is None else np.asarray(count, np.int64))
 
     def __len__(self):
-        return int(sum(p.size for p in self._pos))
+        return int(sum(int(c.sum()) for c in self._cnt))
 
-    def pairs(self, positions=None):
-        """[(ref_pos, string)] of the events at ``positions`` (all events when None), in insertion order."""
+    def counted_pairs(self, positions=None):
+        """[(ref_pos, string, count)] of the rows at ``positions`` (all rows when None)."""
         out = []
         want = None if positions is None else np.fromiter(positions, np.int64, len(positions))
-        for pos, length, blob in zip(self._pos, self._len, self._blob):
+        for pos, length, blob, cnt in zip(self._pos, self._len, self._blob, self._cnt):
             off = np.cumsum(length) - length
             sel = np.arange(pos.size) if want is None else np.nonzero(np.isin(pos, want))[0]
             raw = blob.tobytes()
             for k in sel.tolist():
                 o = int(off[k])
-                out.append((int(pos[k]), raw[o:o + int(length[k])].decode("ascii")))
+                out.append((int(pos[k]), raw[o:o + int(length[k])].decode("ascii"), int(cnt[k])))
         return out
+
+    def pairs(self, positions=None):
+        """[(ref_pos, string)] of the events at ``positions`` (all events when None), in insertion order."""
+        return [(p, s) for p, s, c in self.counted_pairs(positions) for _ in range(c)]
 
 
 def tally(pairs):

@@ -25,6 +25,7 @@ EXPORTS = [
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
     "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events",
+    "amp_aggregate_ins_events",
 ]
 
 
@@ -181,6 +182,19 @@ class Engine:
         ev = np.zeros(max(int(n.value), 1), abi.INS_EVENT_DTYPE)
         self._chk(self.L.amp_drain_ins_events(self.h, C.byref(n), C.c_void_p(abi.ptr(ev)), C.c_int64(ev.size)), "amp_drain_ins_events")
         return ev[:int(n.value)]
+
+    def aggregate_events(self, dev_reads=None, read_base=0, drain=False):
+        """amp_aggregate_ins_events: the insertion events recorded so far, sorted and run-length encoded ON THE DEVICE ->
+        INS_RUN_DTYPE[n_runs], one record per (ref_pos, allele): a representative event and the number of events.
+        dev_reads None = the batch of the last process() call (still staged on the device)."""
+        n = C.c_int64(0)
+        rdp = C.byref(dev_reads) if dev_reads is not None else None
+        self._chk(self.L.amp_aggregate_ins_events(self.h, rdp, C.c_uint64(read_base), C.c_int(0), C.byref(n), None, C.c_int64(0)),
+                  "amp_aggregate_ins_events")
+        runs = np.zeros(max(int(n.value), 1), abi.INS_RUN_DTYPE)
+        self._chk(self.L.amp_aggregate_ins_events(self.h, rdp, C.c_uint64(read_base), C.c_int(1 if drain else 0), C.byref(n),
+                                                  C.c_void_p(abi.ptr(runs)), C.c_int64(runs.size)), "amp_aggregate_ins_events")
+        return runs[:int(n.value)]
 
     def debug_blocks(self):
         out = np.zeros((4096, 4), np.uint32); nb = C.c_int(0)

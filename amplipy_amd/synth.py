@@ -303,3 +303,39 @@ def random_segments(rng, n, ref_len, primers, weird=0.15, domain_errors=True):
         segs.append(Segment(flag=flag, reference_start=pos, cigar=ops, template_length=tl,
                             query_sequence=seq, query_qualities=qual.tolist()))
     return segs
+
+
+def gather_rows(b, idx):
+    """The rows ``idx`` of batch ``b`` as a new batch (variable-length CIGARs / bases gathered with repeat + cumsum)."""
+    def spans(off):
+        ln = (off[1:] - off[:-1]).astype(np.int64)[idx]
+        new_off = np.zeros(idx.size + 1, np.int64); np.cumsum(ln, out=new_off[1:])
+        src = np.repeat(off[:-1].astype(np.int64)[idx] - new_off[:-1], ln) + np.arange(int(new_off[-1]), dtype=np.int64)
+        return new_off, src
+    co, csrc = spans(b.cig_off)
+    so, ssrc = spans(b.seq_off)
+    seq_nib = np.empty(b.seq.size * 2, np.uint8); seq_nib[0::2] = b.seq >> 4; seq_nib[1::2] = b.seq & 15
+    nib = seq_nib[ssrc]
+    return ReadBatch(b.pos[idx], b.flag[idx], b.tlen[idx], b.lseq[idx], co.astype(np.uint64), b.cig[csrc], so.astype(np.uint64),
+                     ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8), b.qual[ssrc])
+
+
+def make_config5_batch(genome, amps, rep=200, pool_reads=40000, seed=3):
+    """BASELINE config 5 at size: mixed 75-300 bp reads with long soft clips and indel-heavy CIGARs, ``rep`` x ``pool_reads``
+    reads (200 x 40,000 = 8.0 M = 50k x depth).  The pool of make_mixed_segments is gathered ``rep`` times with numpy, every
+    copy shifted by 0..7 positions (seeded) and the whole sorted again, so copies of different reads interleave like the
+    reads of a real pile (``rep`` identical reads in a row would make every tile homogeneous) and packing takes seconds."""
+    pool = ReadBatch.from_segments(sorted(make_mixed_segments(genome, amps, pool_reads, seed=seed), key=lambda s: s.reference_start))
+    rng = np.random.default_rng(5)
+    idx = np.repeat(np.arange(pool.n, dtype=np.int64), rep)
+    jit = rng.integers(0, 8, idx.size).astype(np.int32)
+    order = np.argsort(pool.pos[idx].astype(np.int64) + jit, kind="stable")
+    idx, jit = idx[order], jit[order]
+    b = gather_rows(pool, idx)
+    w = pool.cig
+    refop = np.isin(w & 15, (0, 2, 3, 7, 8))
+    cum = np.concatenate([[0], np.cumsum((w >> 4).astype(np.int64) * refop)])
+    span = cum[pool.cig_off[1:].astype(np.int64)] - cum[pool.cig_off[:-1].astype(np.int64)]
+    ok = pool.pos[idx].astype(np.int64) + jit + span[idx] < genome.size      # (a shifted copy must still end inside the reference)
+    b.pos[:] = pool.pos[idx] + np.where(ok, jit, 0).astype(np.int32)
+    return b

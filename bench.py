@@ -30,6 +30,8 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
   cpu_baseline: the C restatement in oracle/ timed on this host's cores on the same batch, plus the
                 pure-Python restatement on a 100 k-read subsample
   e2e:          file-to-file rates outside the timed region (host pointers, BAM -> calls, BAM -> BAM)
+  extra:        BASELINE configs 3 (100k x depth, 19.9 M reads) and 5 (8.0 M mixed 75-300 bp reads), each as ONE launch behind
+                the timed region: duration of the scan pass alone, roofline fraction, oracle assertion
 """
 import argparse
 import json
@@ -44,7 +46,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-SCAN_KERNELS = {4: "scan pass: k_fast + k_tile<LIST> + k_deferred_heavy",
+SCAN_KERNELS = {0: "scan pass: k_fast (k_fast5 for reads of more than 152 bases) + k_tile<LIST> + k_deferred_heavy",
+                4: "scan pass: k_fast + k_tile<LIST> + k_deferred_heavy", 5: "scan pass: k_fast5 + k_tile<LIST> + k_deferred_heavy",
                 2: "scan pass: k_tile + k_deferred_heavy",
                 3: "scan pass: k_trim + k_scan + k_tile<SPLIT> + k_deferred_heavy", 1: "k_reads_lane"}
 
@@ -62,11 +65,12 @@ def main():
     ap.add_argument("--depth", type=int, default=10000, help="mean coverage (10000 -> 1,993,533 reads): per GPU, or of the whole job with --strong")
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4: one job of --depth partitioned over the ranks (strong scaling)")
     ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
-    ap.add_argument("--variant", type=int, default=4)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = chosen per batch by the library)")
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (each has its own stream, engine and outputs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs behind the timed region (config 3: 100k x depth; config 5: 8.0 M mixed reads)")
     ap.add_argument("--no-comm-overlap", action="store_true", help="multi-rank runs: all-reduce on the work stream, in front of the step's calls (default: on its own stream, under the next step's reads)")
     args = ap.parse_args()
 
@@ -264,7 +268,7 @@ def main():
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.isfile(tf):
-        traffic = json.load(open(tf)).get("depth%d_variant%d" % (args.depth, args.variant))
+        traffic = json.load(open(tf)).get("depth%d_variant%d" % (args.depth, args.variant or 4))
 
     strong_check = None
     if args.strong and rank == 0:
@@ -345,6 +349,71 @@ def main():
         except Exception as ex:      # the legs are extras: never lose the bench line to them
             e2e = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
+    # ---- the other single-GPU configs of BASELINE.json, each as ONE launch checked against the oracle (outside the timed
+    # region; the driver's one run then carries their roofline figures too) ---------------------------------------------
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.strong and args.depth == 10000:
+        extra = {}
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle
+            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("AMPLIPY_CPU_THREADS", "16")))
+
+            def one_launch(db, hb, label):
+                """db: DeviceBatch, hb: the same rows on the host -> dict with the scan pass's duration alone and its roofline
+                fraction; asserts count table, trimmed positions and event count against the sharded oracle."""
+                sl = Slot(db)
+                ms = []
+                for it in range(4):
+                    with torch.cuda.stream(sl.stream):
+                        sl.eng.reset()
+                        sl.eng.process_device(sl.rd, 0, sl.dev_out)
+                        sl.eng.sync()
+                    ms.append(sl.eng.last_kernel_ms()[0])
+                torch.cuda.synchronize()
+                got = sl.table.cpu().numpy().view(np.uint32)
+                h_pos = sl.out["new_pos"].cpu().numpy()
+                h_st = sl.out["status"].cpu().numpy()
+                n_out_ = int(sl.out["new_ncig"].sum().item())
+                cuts = [hb.n * k // cores for k in range(cores + 1)]
+
+                def shard(k):
+                    r = oracle.process(hb.slice(cuts[k], cuts[k + 1]), G, mn, mx, mpl, 20, 4, read_base=cuts[k])
+                    assert np.array_equal(r.trim.status, h_st[cuts[k]:cuts[k + 1]]), label + ": read statuses differ from the oracle"
+                    okr = r.trim.status == 0
+                    assert np.array_equal(r.trim.new_pos[okr], h_pos[cuts[k]:cuts[k + 1]][okr]), label + ": trimmed positions differ from the oracle"
+                    return r.counts, r.events.size
+                with ThreadPoolExecutor(cores) as pool:
+                    parts = list(pool.map(shard, range(cores)))
+                total = np.sum([p[0] for p in parts], axis=0, dtype=np.uint32)
+                assert np.array_equal(got[:G * 6].reshape(G, 6), total), label + ": GPU count table differs from the oracle"
+                assert int(got[G * 6:].sum()) == sum(p[1] for p in parts), label + ": insertion events differ from the oracle"
+                lens = hb.lseq.astype(np.int64)
+                n_cig = int(hb.cig_off[-1])
+                ab = int(hb.n * (16 + 8) + ((lens + 1) // 2).sum() + lens.sum() + 4 * n_cig + 4 * n_out_ + 6 * G * 4 + 2 * G * 4)
+                k_alone = float(np.mean(ms[1:]))
+                sl.eng.close()
+                return {"reads": int(hb.n), "mean_read_len": round(float(lens.mean()), 1), "kernel_ms_alone": round(k_alone, 4),
+                        "ms_per_million_reads": round(k_alone / (hb.n / 1e6), 4), "algorithmic_bytes_per_launch": ab,
+                        "achieved_GBs": round(ab / k_alone / 1e6, 1), "frac_alone": round(ab / k_alone / 1e6 / HBM_PEAK_GBS, 5),
+                        "checked": "count table, read statuses, trimmed positions and event count equal oracle/amplipy_oracle.c on the same %d reads (sharded over %d threads)" % (hb.n, cores)}
+
+            t_x = time.time()
+            d3 = synth_torch.make_amplicon_batch_device(genome, amps, synth.reads_for_depth(100000), seed=1000, device=dev)
+            extra["depth100k"] = one_launch(d3, d3.to_host(), "config 3 (100k x)")
+            extra["depth100k"]["workload"] = "BASELINE config 3: the same genome at 100k x depth, 19,935,333 x 150 bp reads in ONE launch"
+            del d3
+            torch.cuda.empty_cache()
+            h5 = synth.make_config5_batch(genome, amps, 200)
+            d5 = synth_torch.DeviceBatch.from_host(h5, dev)
+            extra["config5"] = one_launch(d5, h5, "config 5")
+            extra["config5"]["workload"] = "BASELINE config 5: 8.0 M mixed 75-300 bp reads, long soft clips, indel-heavy CIGARs (50k x), ONE launch"
+            del d5, h5
+            torch.cuda.empty_cache()
+            extra["seconds"] = round(time.time() - t_x, 1)
+        except Exception as ex:      # the extras never cost the bench line
+            extra["error"] = "%s: %s" % (type(ex).__name__, ex)
+
     if rank == 0:
         total_reads = n_reads * args.steps if not args.strong else job_reads * args.steps
         if not args.strong:
@@ -379,6 +448,7 @@ def main():
                                  "the first kernel of the pass alone (k_fast for variant 4)"},
             "cpu_baseline": cpu,
             "e2e": e2e,
+            "extra": extra,
             "gen_seconds": round(t_gen, 2),
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())

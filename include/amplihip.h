@@ -200,6 +200,22 @@ int amp_get_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap
  * batches, where the text of the events is taken batch by batch.  Call with buf == NULL first for the size, like above. */
 int amp_drain_ins_events(amp_ctx *ctx, int64_t *n, amp_ins_event *buf, int64_t cap);
 void *amp_counts_device_ptr(amp_ctx *ctx);
+/* On-device aggregation of the insertion events recorded since the last amp_reset / drain (the dict
+ * keys of AmpliPy.py:745-748, consumed at A:767-771): the device sorts the events by (ref_pos, allele) and run-length
+ * encodes them.  One amp_ins_run per run of events with the same position and the same allele text: `count` events and one
+ * representative (its text through amp_event_strings).  Two runs may carry the same allele (a 64-bit hash collision between
+ * two alleles of one position and length, never seen): the consumer sums counts by (ref_pos, text); a run never mixes alleles.
+ * reads = the device batch the events' read ids refer to, read_base as given to amp_process_batch* (reads == NULL: the batch
+ * of the last amp_process_batch call, still staged on the device).  buf == NULL: *n_runs = an upper bound (list slots in
+ * use); buf != NULL (cap >= that bound): the records, *n_runs = their number, sorted by (ref_pos, allele length).
+ * drain != 0: the event list is empty afterwards (the per-position tally of amp_get_counts stays). */
+typedef struct amp_ins_run {
+    amp_ins_event first;
+    uint32_t count;
+    uint32_t reserved;
+} amp_ins_run;
+int amp_aggregate_ins_events(amp_ctx *ctx, const amp_dev_reads *reads, uint64_t read_base, int drain, int64_t *n_runs,
+                             amp_ins_run *buf, int64_t cap);
 /* Sum the device tables (counts + insertion tally) over the ranks of an RCCL communicator (ncclComm_t) onto rank `root`
  * (root < 0: all ranks).  comm == NULL is a no-op (single GPU). */
 int amp_reduce(amp_ctx *ctx, void *rccl_comm, int root);

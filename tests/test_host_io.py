@@ -107,3 +107,19 @@ def test_event_store_matches_per_event_strings():
     some = set(p for p, _ in want[::7])
     assert st.pairs(some) == [x for x in want if x[0] in some]
     assert st.pairs(set()) == []
+
+
+def test_event_store_with_run_counts_and_tallies():
+    """Rows that stand for several events (the (position, allele) runs of amp_aggregate_ins_events): the store
+    keeps their counts, and calling.tallies_from_runs sums rows of one allele (a run may be split, never mixed)."""
+    from collections import Counter
+    from amplipy_amd import calling, insertions
+    st = insertions.EventStore()
+    st.add_text([5, 5, 9], [2, 3, 2], np.frombuffer(b"ATATTAC", np.uint8), [4, 1, 2])
+    st.add_text([5], [2], np.frombuffer(b"AT", np.uint8), [3])                 # the same allele again (another batch, or a split run)
+    assert len(st) == 10
+    assert st.counted_pairs() == [(5, "AT", 4), (5, "ATT", 1), (9, "AC", 2), (5, "AT", 3)]
+    assert Counter(st.pairs()) == Counter({(5, "AT"): 7, (5, "ATT"): 1, (9, "AC"): 2})
+    t = calling.tallies_from_runs(st.counted_pairs({5}), {5})
+    assert dict(t[5]) == {"AT": 7, "ATT": 1} and 9 not in t
+    assert calling.tallies_from_runs(st.counted_pairs(), {9})[9] == {"AC": 2}

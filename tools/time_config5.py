@@ -10,40 +10,11 @@ from amplipy_amd import lib, synth
 from amplipy_amd.batch import ReadBatch
 
 
-def gather_rows(b, idx):
-    """The rows idx of batch b as a new batch (variable-length CIGARs / bases gathered with repeat + cumsum)."""
-    def spans(off, unit_pad=1):
-        ln = (off[1:] - off[:-1]).astype(np.int64)[idx]
-        new_off = np.zeros(idx.size + 1, np.int64); np.cumsum(ln, out=new_off[1:])
-        src = np.repeat(off[:-1].astype(np.int64)[idx] - new_off[:-1], ln) + np.arange(int(new_off[-1]), dtype=np.int64)
-        return new_off, src
-    co, csrc = spans(b.cig_off)
-    so, ssrc = spans(b.seq_off)
-    seq_nib = np.empty(b.seq.size * 2, np.uint8); seq_nib[0::2] = b.seq >> 4; seq_nib[1::2] = b.seq & 15
-    nib = seq_nib[ssrc]
-    return ReadBatch(b.pos[idx], b.flag[idx], b.tlen[idx], b.lseq[idx], co.astype(np.uint64), b.cig[csrc], so.astype(np.uint64),
-                     ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8), b.qual[ssrc])
-
-
 rep = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
 pr = [(s, e) for s, e, _ in primers]
-pool = ReadBatch.from_segments(sorted(synth.make_mixed_segments(g, amps, 40000, seed=3), key=lambda s: s.reference_start))
 t = time.time()
-# every pool read rep times, each copy shifted by 0..7 positions (seeded) and the batch sorted again: copies of different
-# reads interleave like the reads of a real pile (rep identical reads in a row would make every tile homogeneous)
-rng = np.random.default_rng(5)
-idx = np.repeat(np.arange(pool.n, dtype=np.int64), rep)
-jit = rng.integers(0, 8, idx.size).astype(np.int32)
-order = np.argsort(pool.pos[idx].astype(np.int64) + jit, kind="stable")
-idx, jit = idx[order], jit[order]
-b = gather_rows(pool, idx)
-span = np.zeros(pool.n, np.int64)
-for i in range(pool.n):
-    w = pool.cig[int(pool.cig_off[i]):int(pool.cig_off[i + 1])]
-    span[i] = int(((w >> 4) * np.isin(w & 15, (0, 2, 3, 7, 8))).sum())
-ok = pool.pos[idx].astype(np.int64) + jit + span[idx] < g.size          # (a shifted copy must still end inside the reference)
-b.pos[:] = pool.pos[idx] + np.where(ok, jit, 0).astype(np.int32)
+b = synth.make_config5_batch(g, amps, rep)
 assert np.all(np.diff(b.pos.astype(np.int64)) >= -7)
 nops = np.diff(b.cig_off.astype(np.int64))
 print("packed %d reads in %.1f s: %.1f M bases, mean length %.0f, mean CIGAR ops %.1f (max %d), %.1f %% with an indel or more than one op"
