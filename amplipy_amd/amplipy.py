@@ -106,8 +106,21 @@ def open_alignment_files(input_fn, output_fn):
     return reader, writer
 
 
-def open_native_bam(input_fn, output_fn):
-    """(BamFile, BamWriter or None) when the native codec can serve this run: BAM file in, and BAM file
+NATIVE_PART_BYTES = 16 << 20       # compressed bytes of a piece of the input BAM (pieces are inflated one ahead of the GPU)
+
+
+def native_parts(input_fn, rank=0, world=1, part_bytes=None):
+    """How a BAM file is cut for this rank: (n_parts, k_lo, k_hi) -- the file has n_parts pieces of about ``part_bytes``
+    compressed bytes (ampbam_open_range: cut at BGZF block starts, i.e. by base count for a sorted BAM), of which the rank
+    takes the contiguous run [k_lo, k_hi).  Every rank gets the same number of pieces (n_parts is a multiple of world)."""
+    part_bytes = part_bytes or int(os.environ.get("AMPLIPY_PART_BYTES", NATIVE_PART_BYTES))
+    size = os.path.getsize(input_fn)
+    per_rank = max(1, -(-size // (part_bytes * world)))
+    return per_rank * world, per_rank * rank, per_rank * (rank + 1)
+
+
+def open_native_bam(input_fn, output_fn, rank=0, world=1):
+    """(NativeInput, BamWriter or None) when the native codec can serve this run: BAM file in, and BAM file
     (or nothing) out.  None otherwise (SAM text, stdin / stdout): the Python codec handles those.
     Same checks and messages as open_alignment_files."""
     if input_fn is None or input_fn.lower() == "stdin" or not isfile(input_fn) or _reads_mode(input_fn, False) != "rb":
@@ -116,14 +129,81 @@ def open_native_bam(input_fn, output_fn):
         return None
     if os.environ.get("AMPLIPY_PYTHON_BAM"):
         return None
-    from . import bam_native
-    src = bam_native.BamFile(input_fn)
+    src = NativeInput(input_fn, rank, world)
     writer = None
     if output_fn is not None:
-        hdr = bamio.Header(src.header_text, src.references).with_amplipy_pg(VERSION, " ".join(sys.argv))
+        from . import bam_native
+        first = src.first_part()
+        hdr = bamio.Header(first.header_text, first.references).with_amplipy_pg(VERSION, " ".join(sys.argv))
         # zlib's default level like htslib; AMPLIPY_BAM_LEVEL=1 trades file size for speed
-        writer = bam_native.BamWriter(output_fn, hdr.text, src, level=int(os.environ.get("AMPLIPY_BAM_LEVEL", "-1")))
+        writer = bam_native.BamWriter(output_fn, hdr.text, first, level=int(os.environ.get("AMPLIPY_BAM_LEVEL", "-1")))
     return src, writer
+
+
+class NativeInput:
+    """The rank's share of a BAM file as a sequence of pieces (bam_native.BamFile of ampbam_open_range), each inflated and
+    indexed on a helper thread while the piece before it is on the GPU (AmpliPy.py:896 streams its input; here at most two
+    pieces are in memory).  Pieces must meet: each starts where the one before ended (checked; ranks check their seams with
+    each other through ``seam``)."""
+
+    def __init__(self, path, rank=0, world=1):
+        self.path = path
+        self.n_parts, self.k_lo, self.k_hi = native_parts(path, rank, world)
+        self._first = None
+        self._ahead = None          # (thread, box) of the piece being opened
+
+    def _open(self, k):
+        from . import bam_native
+        return bam_native.BamFile(self.path, part=k, n_parts=self.n_parts)
+
+    def first_part(self):
+        if self._first is None:
+            self._first = self._open(self.k_lo)
+        return self._first
+
+    def _start(self, k):
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["file"] = self._open(k)
+            except Exception as e:           # surfaced by the consumer
+                box["error"] = e
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        self._ahead = (t, box)
+
+    def __iter__(self):
+        """Yields the pieces in order; the caller closes each when it is done with it.  seam = (first, end) of the whole
+        share is available afterwards."""
+        prev_end = None
+        self.seam = [None, None]
+        cur = self.first_part()
+        self._first = None
+        for k in range(self.k_lo, self.k_hi):
+            if k + 1 < self.k_hi:
+                self._start(k + 1)
+            if cur.n_records:
+                a, b = cur.part_range()
+                if prev_end is not None and a != prev_end:
+                    raise bam_native_error("%s: piece %d of %d starts at inflated offset %d, the piece before it ended at %d"
+                                           % (self.path, k, self.n_parts, a, prev_end))
+                if self.seam[0] is None:
+                    self.seam[0] = a
+                self.seam[1] = prev_end = b
+            yield cur
+            if k + 1 < self.k_hi:
+                t, box = self._ahead
+                t.join()
+                if "error" in box:
+                    raise box["error"]
+                cur = box["file"]
+
+
+def bam_native_error(msg):
+    from . import bam_native
+    return bam_native.AmpBamError(msg)
 
 
 class VcfWriter:
@@ -249,12 +329,12 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
     if run_trim:
         print_log("Input untrimmed SAM/BAM: %s" % untrimmed_reads_fn)
         print_log("Output trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        native = open_native_bam(untrimmed_reads_fn, trimmed_reads_fn)
+        native = open_native_bam(untrimmed_reads_fn, trimmed_reads_fn, rank, world)
         if native is None:
             reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
     else:
         print_log("Input trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        native = open_native_bam(trimmed_reads_fn, None)
+        native = open_native_bam(trimmed_reads_fn, None, rank, world)
         if native is None:
             reader, writer = open_alignment_files(trimmed_reads_fn, None)
     vcf = None
@@ -266,6 +346,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                    sliding_window_width if sliding_window_width is not None else 4, run_trim, do_count)
 
     print_log("Processing reads...")
+    rank_error = None
     ins_store = EventStore()             # insertion events with their allele text (each batch's bases are at hand only now)
     pending = []
     s_i = None
@@ -293,80 +374,119 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         read_base += batch.n
         del pending[:]
 
+    n_seen = 0                           # records this rank has gone through (all of them when there is one rank)
     if native is not None:
         # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
-        # re-encodes the kept ones; no per-read Python object exists on this path
+        # re-encodes the kept ones; no per-read Python object exists on this path.  The file is walked piece by piece:
+        # piece k + 1 is inflated and indexed on a helper thread while piece k is decoded, trimmed and counted, and a
+        # writer thread re-encodes and deflates the rows of piece k - 1 (every stage is a C call that releases the GIL;
+        # rows stay in order)
         src, nwriter = native
-        # re-encoding + deflate is the longest stage: a writer thread takes batch k while this thread
-        # decodes and runs batch k+1 (every stage is a C call that releases the GIL; rows stay in order)
         wq = werr = wthread = None
         if run_trim and nwriter is not None:
             import queue
             import threading
-            wq = queue.Queue(maxsize=2); werr = []
+            wq = queue.Queue(maxsize=3); werr = []
 
             def _writer():
                 while True:
                     job = wq.get()
                     if job is None:
                         return
-                    if not werr:
-                        try:
-                            nwriter.write_rows(*job)
-                        except Exception as e:       # surfaced by the main thread
-                            werr.append(e)
+                    try:
+                        if job[0] == "close":
+                            job[1].close()
+                        elif not werr:
+                            nwriter.write_rows(*job[1:])
+                    except Exception as e:       # surfaced by the main thread
+                        werr.append(e)
             wthread = threading.Thread(target=_writer, daemon=True); wthread.start()
         try:
-            rec_lo, rec_hi = (src.n_records * rank) // world, (src.n_records * (rank + 1)) // world   # this rank's records
-            for first in range(rec_lo, rec_hi, NATIVE_BATCH_READS):
-                count = min(NATIVE_BATCH_READS, rec_hi - first)
-                batch, _ = src.decode(first, count)
-                for s_i in range(first + (-first) % PROGRESS_NUM_READS, first + count, PROGRESS_NUM_READS):
-                    if s_i:
-                        print_log("Processed %d reads..." % s_i)
-                s_i = first + count - 1
-                if batch.n == 0:
-                    continue
-                res = eng.process(batch, read_base=read_base)
-                bad = np.nonzero(res.status)[0]
-                if wq is not None:
-                    if werr:
-                        raise werr[0]
-                    keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
+            for piece in src:
+                for first in range(0, piece.n_records, NATIVE_BATCH_READS):
+                    count = min(NATIVE_BATCH_READS, piece.n_records - first)
+                    batch, _ = piece.decode(first, count)
+                    for k_ in range(n_seen + (-n_seen) % PROGRESS_NUM_READS, n_seen + count, PROGRESS_NUM_READS):
+                        if k_:
+                            print_log("Processed %d reads..." % k_)
+                    n_seen += count
+                    s_i = n_seen - 1
+                    if batch.n == 0:
+                        continue
+                    res = eng.process(batch, read_base=read_base)
+                    bad = np.nonzero(res.status)[0]
+                    if wq is not None:
+                        if werr:
+                            raise werr[0]
+                        keep = (res.ref_len >= min_length) & (((res.trim_flags & 3) != 0) | bool(include_no_primer))   # AmpliPy.py:910
+                        if len(bad):
+                            keep[int(bad[0]):] = False          # the reads in front of the failing one are still written (A:907-911)
+                        slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
+                        # src_index is a view of the decoder's buffers, which the next decode overwrites
+                        wq.put(("rows", piece, batch.src_index.copy(), keep, res.new_pos, res.new_ncig, slot_off, res.new_cig))
                     if len(bad):
-                        keep[int(bad[0]):] = False          # the reads in front of the failing one are still written (A:907-911)
-                    slot_off = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
-                    # src_index is a view of the decoder's buffers, which the next decode overwrites
-                    wq.put((batch.src_index.copy(), keep, res.new_pos, res.new_ncig, slot_off, res.new_cig))
-                if len(bad):
-                    _raise_for_status(res.status[bad[0]])
-                if do_count:
-                    _store_events(eng, ins_store, read_base)
-                read_base += batch.n
+                        _raise_for_status(res.status[bad[0]])
+                    if do_count:
+                        _store_events(eng, ins_store, read_base)
+                    read_base += batch.n
+                if wq is not None:
+                    wq.put(("close", piece))        # (the writer copies the unchanged parts of a record from the piece's image)
+                else:
+                    piece.close()
+        except Exception as e:                      # with several ranks the others must not be left waiting in the collective
+            if dist is None:
+                raise
+            rank_error = e
         finally:
             if wq is not None:
                 wq.put(None)
                 wthread.join()
-        if werr:
-            raise werr[0]
-        if nwriter is not None:
+        if werr and rank_error is None:
+            if dist is None:
+                raise werr[0]
+            rank_error = werr[0]
+        if nwriter is not None and rank_error is None:
             nwriter.close()
-        src.close()
+        seam = getattr(src, "seam", [None, None])
     else:
-        for s_i, rec in enumerate(reader):
-            if s_i % PROGRESS_NUM_READS == 0 and s_i != 0:
-                print_log("Processed %d reads..." % s_i)
-            if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
-                continue
-            if world > 1 and s_i % world != rank:              # text input has no record index: deal the reads out
-                continue
-            pending.append(rec)
-            if len(pending) >= BATCH_READS:
-                flush()
-        flush()
-        if writer is not None:
-            writer.close()
-        reader.close()
+        seam = [None, None]
+        try:
+            for s_i, rec in enumerate(reader):
+                if s_i % PROGRESS_NUM_READS == 0 and s_i != 0:
+                    print_log("Processed %d reads..." % s_i)
+                if (rec.flag & 4) or rec.cigar is None:            # AmpliPy.py:902
+                    continue
+                if world > 1 and s_i % world != rank:              # text input has no record index: deal the reads out
+                    continue
+                pending.append(rec)
+                if len(pending) >= BATCH_READS:
+                    flush()
+            flush()
+            if writer is not None:
+                writer.close()
+            reader.close()
+        except Exception as e:
+            if dist is None:
+                raise
+            rank_error = e
+
+    if dist is not None:
+        # before the one collective of the run: did every rank get through its share (a rank that raised must not leave the
+        # others waiting in the all-reduce), and do the shares of neighbouring ranks meet (every share of a BAM file starts
+        # where the one before it ended: what makes the split of ampbam_open_range exact)
+        notes = [None] * world
+        dist.all_gather_object(notes, (seam, None if rank_error is None else "%s: %s" % (type(rank_error).__name__, rank_error)))
+        errs = [e_ for _, e_ in notes if e_]
+        ends = [sm for sm, _ in notes if sm[0] is not None]
+        bad_seam = next(((x[1], y[0]) for x, y in zip(ends[:-1], ends[1:]) if x[1] != y[0]), None)
+        if errs or bad_seam:
+            eng.close()
+            parallel.finish(dist)
+            if rank_error is not None:
+                raise rank_error
+            if errs:
+                raise RuntimeError("another rank failed: %s" % errs[0])
+            raise bam_native_error("the shares of two ranks do not meet (inflated offsets %d / %d)" % bad_seam)
 
     if do_count:
         cp = calling.call_params(min_depth_consensus if min_depth_consensus is not None else 0,
@@ -398,7 +518,9 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
     eng.close()
     parallel.finish(dist)
     if s_i is None:
-        raise NameError("name 's_i' is not defined")       # the reference's behaviour on an empty input (:963)
+        if dist is None or world == 1:
+            raise NameError("name 's_i' is not defined")       # the reference's behaviour on an empty input (:963)
+        s_i = -1                                               # (a rank whose share is empty: more ranks than pieces of the file)
     print_log("Finished Processing %d reads" % s_i)
 
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libampbam.so")
 EXPORTS = [
     "ampbam_version", "ampbam_strerror", "ampbam_open", "ampbam_close", "ampbam_last_error", "ampbam_n_records",
     "ampbam_header_text", "ampbam_n_refs", "ampbam_ref", "ampbam_decode", "ampbam_writer_open", "ampbam_write_rows",
-    "ampbam_writer_close",
+    "ampbam_writer_close", "ampbam_open_range", "ampbam_part_range",
 ]
 _LIB = None
 
@@ -62,10 +62,13 @@ def _view(addr, dtype, count):
 class BamFile:
     """A BAM file inflated into host memory; records are addressed by number."""
 
-    def __init__(self, path, threads=0):
+    def __init__(self, path, threads=0, part=0, n_parts=1):
+        """part / n_parts: only that share of the file (ampbam_open_range: cut by compressed bytes at BGZF-block starts; records
+        are numbered from the part's first one)."""
         self.L = load()
         h = C.c_void_p()
-        rc = self.L.ampbam_open(os.fsencode(path), C.c_int(threads), C.byref(h))
+        self.part, self.n_parts = int(part), int(n_parts)
+        rc = self.L.ampbam_open_range(os.fsencode(path), C.c_int(threads), C.c_int(part), C.c_int(n_parts), C.byref(h))
         if rc:
             raise AmpBamError("%s: %s" % (path, self.L.ampbam_strerror(rc).decode()))
         self.h = h
@@ -79,6 +82,13 @@ class BamFile:
             nm = C.c_char_p(); ln = C.c_int32()
             self.L.ampbam_ref(h, C.c_int32(i), C.byref(nm), C.byref(ln))
             self.references.append((nm.value.decode("ascii"), int(ln.value)))
+
+    def part_range(self):
+        """(first, end): offsets in the file's inflated stream of this part's first record and of the byte behind its last one.
+        Neighbouring parts must meet: part k + 1 starts where part k ended (the check that makes the split exact)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.ampbam_part_range(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def decode(self, first, count, copy=False):
         """Records [first, first+count) -> (ReadBatch of the rows AmpliPy.py:902 keeps, n_skipped).
@@ -122,11 +132,14 @@ class BamWriter:
             raise AmpBamError("%s: %s" % (path, self.L.ampbam_strerror(rc).decode()))
         self.h = h
 
-    def write_rows(self, src_index, keep, new_pos, new_ncig, new_cig_off, new_cig):
+    def write_rows(self, src, src_index, keep, new_pos, new_ncig, new_cig_off, new_cig):
+        """Rows of a batch decoded from ``src`` (the input file, or the piece of it the batch came from; None: the file the
+        writer was opened with)."""
+        src = self.src if src is None else src
         src_index = np.ascontiguousarray(src_index, np.int64); keep = np.ascontiguousarray(keep, np.uint8)
         new_pos = np.ascontiguousarray(new_pos, np.int32); new_ncig = np.ascontiguousarray(new_ncig, np.uint32)
         new_cig_off = np.ascontiguousarray(new_cig_off, np.uint64); new_cig = np.ascontiguousarray(new_cig, np.uint32)
-        rc = self.L.ampbam_write_rows(self.h, self.src.h, C.c_int64(src_index.size), C.c_void_p(src_index.ctypes.data),
+        rc = self.L.ampbam_write_rows(self.h, src.h, C.c_int64(src_index.size), C.c_void_p(src_index.ctypes.data),
                                       C.c_void_p(keep.ctypes.data), C.c_void_p(new_pos.ctypes.data),
                                       C.c_void_p(new_ncig.ctypes.data), C.c_void_p(new_cig_off.ctypes.data),
                                       C.c_void_p(new_cig.ctypes.data))

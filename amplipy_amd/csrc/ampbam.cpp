@@ -149,6 +149,11 @@ struct ampbam_file {
     std::vector<uint64_t> rec_info;         // l_seq | n_cigar_op << 32 | flag << 48, so that planning a batch does not touch the image
     int n_threads = 1;
     std::string err;
+    // ampbam_open_range: the part's place in the whole inflated stream
+    uint64_t img_base = 0;                  // inflated offset of data[0]
+    uint64_t part_first = 0, part_end = 0;  // inflated offsets: this part's first record; one past its last record
+    Bytes hdr;                              // header bytes of parts that do not start at the file's first block
+    const uint8_t *text_ptr = nullptr;
     // decode outputs (reused)
     std::vector<int32_t> pos, tlen;
     std::vector<uint16_t> flag;
@@ -332,7 +337,7 @@ int64_t ampbam_n_records(const ampbam_file *f) { return f ? (int64_t)f->rec_off.
 
 int ampbam_header_text(const ampbam_file *f, const char **text, int64_t *len) {
     if (!f || !text || !len) return AMPBAM_EINVAL;
-    *text = (const char *)f->data.data() + f->text_off;
+    *text = f->text_ptr ? (const char *)f->text_ptr : (const char *)f->data.data() + f->text_off;
     size_t n = f->text_len;
     while (n && (*text)[n - 1] == '\0') --n;      // some writers NUL-pad the text
     *len = (int64_t)n;
@@ -402,6 +407,242 @@ int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *ou
     out->n_skipped = count - n;
     return AMPBAM_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// one part of a BAM file (range partition of a run over ranks, or a file read piece by piece)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct MappedFile {
+    const uint8_t *p = nullptr; size_t n = 0;
+    ~MappedFile() { if (p && n) munmap(const_cast<uint8_t *>(p), n); }
+    int map(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return AMPBAM_EIO;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 0) { ::close(fd); return AMPBAM_EIO; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); n = 0; return AMPBAM_EIO; }
+            p = (const uint8_t *)m;
+        }
+        ::close(fd);
+        return AMPBAM_OK;
+    }
+};
+
+// the BGZF block table of a mapped file (a serial hop over the block headers; nothing is inflated)
+int block_table(const MappedFile &raw, std::vector<Block> &blocks, size_t &total) {
+    size_t p = 0;
+    total = 0;
+    while (p < raw.n) {
+        if (raw.n - p < 18 || raw.p[p] != 0x1f || raw.p[p + 1] != 0x8b || raw.p[p + 2] != 8 || !(raw.p[p + 3] & 4)) return AMPBAM_EFORMAT;
+        const size_t xlen = le16(&raw.p[p + 10]);
+        if (raw.n - p < 12 + xlen) return AMPBAM_EFORMAT;
+        size_t bsize = 0, q = p + 12;
+        const size_t xend = p + 12 + xlen;
+        while (q + 4 <= xend) {
+            const size_t slen = le16(&raw.p[q + 2]);
+            if (raw.p[q] == 'B' && raw.p[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)le16(&raw.p[q + 4]) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || raw.n - p < bsize) return AMPBAM_EFORMAT;
+        Block b;
+        b.in_off = p + 12 + xlen; b.in_len = bsize - 12 - xlen - 8;
+        b.crc = le32(&raw.p[p + bsize - 8]); b.out_len = le32(&raw.p[p + bsize - 4]);
+        b.out_off = total;
+        if (b.out_len > 65536) return AMPBAM_EFORMAT;
+        total += b.out_len;
+        blocks.push_back(b);
+        p += bsize;
+    }
+    return AMPBAM_OK;
+}
+
+// Does a plausible BAM record start at d[o]?  (SAMv1 4.2: block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag,
+// l_seq, next_refID, next_pos, tlen, read_name NUL-terminated, CIGAR ops 0..8.)  *next = offset behind it.
+bool plausible_record(const uint8_t *d, size_t avail, size_t o, int32_t n_ref, size_t *next) {
+    if (o + 36 > avail) return false;
+    const size_t bs = le32(d + o);
+    if (bs < 32 || bs > (1u << 27)) return false;
+    const uint8_t *c = d + o + 4;
+    const int32_t ref_id = (int32_t)le32(c), pos = (int32_t)le32(c + 4), next_ref = (int32_t)le32(c + 20), next_pos = (int32_t)le32(c + 24);
+    const uint32_t l_name = c[8], n_cig = le16(c + 12), l_seq = le32(c + 16);
+    if (ref_id < -1 || ref_id >= n_ref || next_ref < -1 || next_ref >= n_ref || pos < -1 || next_pos < -1 || l_name < 1) return false;
+    if (32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs) return false;
+    if (o + 4 + 32 + l_name + 4ull * n_cig > avail) { *next = o + 4 + bs; return true; }      // the fixed part is all we can see
+    if (c[32 + l_name - 1] != 0) return false;
+    for (uint32_t k = 0; k + 1 < l_name; ++k) if (c[32 + k] < 33 || c[32 + k] > 126) return false;
+    for (uint32_t k = 0; k < n_cig; ++k) if ((le32(c + 32 + l_name + 4 * k) & 15u) > 8u) return false;
+    *next = o + 4 + bs;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ampbam.h: part `part` of `n_parts` of the file.  The cut points are compressed-byte offsets rounded up to BGZF block
+// starts (for a coordinate-sorted BAM of similar reads: equal shares of bases); a part owns the records that START inside
+// its blocks.  Where the first record of a part starts is not written anywhere in a BAM file: it is found by looking for
+// the first offset from which a chain of plausible records runs (what splitting BAM readers do), and the caller makes it
+// exact by checking that every part's first record starts where the part before it ended (ampbam_part_range).
+int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, ampbam_file **out) {
+    if (!path || !out || n_parts < 1 || part < 0 || part >= n_parts) return AMPBAM_EINVAL;
+    if (n_parts == 1) return ampbam_open(path, n_threads, out);
+    *out = nullptr;
+    MappedFile raw;
+    int rc = raw.map(path);
+    if (rc) return rc;
+    std::vector<Block> blocks;
+    size_t total = 0;
+    rc = block_table(raw, blocks, total);
+    if (rc) return rc;
+    const int64_t nb = (int64_t)blocks.size();
+    if (nb == 0) return AMPBAM_EFORMAT;
+    ampbam_file *f = new (std::nothrow) ampbam_file();
+    if (!f) return AMPBAM_ENOMEM;
+    f->n_threads = pick_threads(n_threads);
+    auto fail = [&](int r) { delete f; return r; };
+    auto cut = [&](int k) -> int64_t {                    // first block at or behind share k of the compressed bytes
+        if (k <= 0) return 0;
+        if (k >= n_parts) return nb;
+        const size_t want = (size_t)((unsigned __int128)raw.n * (unsigned)k / (unsigned)n_parts);
+        int64_t lo = 0, hi = nb;
+        while (lo < hi) { const int64_t m = (lo + hi) / 2; if (blocks[(size_t)m].in_off >= want) hi = m; else lo = m + 1; }
+        return lo;
+    };
+    const int64_t b_lo = cut(part), b_hi = cut(part + 1);
+    // ---- the header: from the file's first blocks (a few KB), whatever the part -------------------------------------
+    int32_t n_ref = 0;
+    size_t hdr_end = 0;                                  // inflated offset behind the reference dictionary
+    {
+        Inflater inf;
+        size_t have = 0;
+        int64_t k = 0;
+        auto more = [&]() -> bool {
+            if (k >= nb) return false;
+            const Block &b = blocks[(size_t)k++];
+            if (!f->hdr.resize(have + b.out_len + 16)) return false;
+            if (b.out_len && !inf.run(raw.p + b.in_off, b.in_len, f->hdr.data() + have, b.out_len, b.crc)) return false;
+            have += b.out_len;
+            return true;
+        };
+        auto need = [&](size_t upto) { while (have < upto) if (!more()) return false; return true; };
+        if (!need(12) || std::memcmp(f->hdr.data(), "BAM\1", 4) != 0) return fail(AMPBAM_EFORMAT);
+        const size_t l_text = le32(f->hdr.data() + 4);
+        if (!need(12 + l_text)) return fail(AMPBAM_EFORMAT);
+        size_t o = 8 + l_text;
+        n_ref = (int32_t)le32(f->hdr.data() + o); o += 4;
+        if (n_ref < 0) return fail(AMPBAM_EFORMAT);
+        for (int32_t r = 0; r < n_ref; ++r) {
+            if (!need(o + 4)) return fail(AMPBAM_EFORMAT);
+            const size_t l_name = le32(f->hdr.data() + o); o += 4;
+            if (l_name == 0 || !need(o + l_name + 4)) return fail(AMPBAM_EFORMAT);
+            f->ref_names.emplace_back((const char *)(f->hdr.data() + o), l_name - 1); o += l_name;
+            f->ref_lens.push_back((int32_t)le32(f->hdr.data() + o)); o += 4;
+        }
+        f->text_off = 8; f->text_len = l_text;
+        f->text_ptr = f->hdr.data() + 8;
+        hdr_end = o;
+    }
+    // ---- inflate the part's blocks, and behind them as many as its last record needs -----------------------------------
+    const uint64_t end_off = b_hi < nb ? blocks[(size_t)b_hi].out_off : total;      // records that start below this are the part's
+    int64_t b_ext = std::min<int64_t>(nb, b_hi + 2);
+    f->img_base = b_lo < nb ? blocks[(size_t)b_lo].out_off : total;
+    f->part_first = f->part_end = f->img_base;
+    int64_t inflated_to = b_lo;
+    auto inflate_to = [&](int64_t upto) -> int {          // data covers blocks [b_lo, upto)
+        upto = std::min<int64_t>(upto, nb);
+        if (upto <= inflated_to) return AMPBAM_OK;
+        const size_t bytes = (size_t)((upto < nb ? blocks[(size_t)upto].out_off : total) - f->img_base);
+        if (!f->data.resize(bytes + 16)) return AMPBAM_ENOMEM;
+        std::memset(f->data.data() + bytes, 0, 16);
+        std::atomic<int> bad{0};
+        const int64_t first = inflated_to, cnt = upto - inflated_to, grain = 8;
+        parallel_for(f->n_threads, (cnt + grain - 1) / grain, [&](int64_t ch) {
+            Inflater local;
+            for (int64_t k = first + ch * grain; k < std::min(upto, first + (ch + 1) * grain); ++k) {
+                const Block &b = blocks[(size_t)k];
+                if (b.out_len && !local.run(raw.p + b.in_off, b.in_len, f->data.data() + (b.out_off - f->img_base), b.out_len, b.crc)) bad = 1;
+            }
+        });
+        if (bad) return AMPBAM_EFORMAT;
+        inflated_to = upto;
+        return AMPBAM_OK;
+    };
+    if (b_lo >= nb || b_lo >= b_hi) {                     // an empty part (more parts than blocks)
+        f->rec_off.push_back(0);
+        *out = f;
+        return AMPBAM_OK;
+    }
+    rc = inflate_to(b_ext);
+    if (rc) return fail(rc);
+    // ---- the part's first record ------------------------------------------------------------------------------------------
+    size_t o;                                             // offset in data
+    if (part == 0) {
+        if (hdr_end < f->img_base) return fail(AMPBAM_EFORMAT);
+        o = hdr_end - (size_t)f->img_base;
+    } else {
+        // a record that starts in front of this part may end anywhere in its first blocks: the first offset from which 64
+        // plausible records follow each other (or run to the end of what is inflated)
+        const size_t avail = f->data.size() - 16;
+        const size_t limit = std::min<size_t>(avail, (size_t)(end_off - f->img_base));
+        bool found = false;
+        for (size_t cand = 0; cand < limit && !found; ++cand) {
+            size_t at = cand, nx = 0;
+            int chain = 0;
+            while (chain < 64 && at + 36 <= avail && plausible_record(f->data.data(), avail, at, n_ref, &nx)) { at = nx; ++chain; }
+            if (chain >= 64 || (chain >= 1 && at + 36 > avail)) { o = cand; found = true; }
+        }
+        if (!found) {                                      // no record starts in this part (one huge record spans it)
+            f->part_first = f->part_end = end_off;
+            f->rec_off.push_back(0);
+            *out = f;
+            return AMPBAM_OK;
+        }
+    }
+    f->part_first = f->img_base + o;
+    // ---- index the records that start inside the part ---------------------------------------------------------------------
+    try {
+        const size_t lim = (size_t)(end_off - f->img_base);
+        while (o < lim) {
+            if (o + 36 > f->data.size() - 16) { rc = inflate_to(inflated_to + 4); if (rc) return fail(rc); if (o + 36 > f->data.size() - 16) return fail(AMPBAM_EFORMAT); }
+            const uint8_t *d = f->data.data();
+            const size_t bs = le32(d + o);
+            if (bs < 32) return fail(AMPBAM_EFORMAT);
+            while (o + 4 + bs > f->data.size() - 16) {
+                if (inflated_to >= nb) return fail(AMPBAM_EFORMAT);
+                rc = inflate_to(inflated_to + std::max<int64_t>(4, (int64_t)(bs / 60000)));
+                if (rc) return fail(rc);
+            }
+            d = f->data.data();
+            const uint8_t *c = d + o + 4;
+            const uint64_t n_cig = le16(c + 12), flag = le16(c + 14), l_seq = le32(c + 16), l_name = c[8];
+            if (32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq > bs) return fail(AMPBAM_EFORMAT);
+            f->rec_off.push_back(o);
+            f->rec_info.push_back(l_seq | (n_cig << 32) | (flag << 48));
+            o += 4 + bs;
+        }
+    } catch (const std::bad_alloc &) { return fail(AMPBAM_ENOMEM); }
+    f->rec_off.push_back(o);
+    f->part_end = f->img_base + o;
+    *out = f;
+    return AMPBAM_OK;
+}
+
+int ampbam_part_range(const ampbam_file *f, uint64_t *first, uint64_t *end) {
+    if (!f || !first || !end) return AMPBAM_EINVAL;
+    *first = f->part_first; *end = f->part_end;
+    return AMPBAM_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------
 // writer

@@ -41,6 +41,18 @@ const char *ampbam_strerror(int rc);
 /* Reads `path`, inflates all BGZF blocks with `n_threads` workers (<= 0: one per available CPU,
  * at most 16), checks each block's CRC32, parses the header and indexes the records. */
 int ampbam_open(const char *path, int n_threads, ampbam_file **out);
+/* Part `part` of `n_parts` of the file (0 <= part < n_parts): a rank of a multi-GPU run inflates only its share, and a
+ * single process can walk a file piece by piece with bounded memory (AmpliPy.py:896 streams).  The cut points are
+ * compressed-byte offsets rounded up to BGZF block starts -- equal shares of bases for a coordinate-sorted BAM of similar
+ * reads -- and a part owns the records that START inside its blocks (the blocks its last record runs into are inflated too).
+ * A BAM file does not say where records start inside a block: the first record of a part > 0 is the first offset from which
+ * a chain of 64 plausible records runs.  To make that exact, compare neighbours with ampbam_part_range: part k + 1 must
+ * start where part k ended (a mismatch: fall back to ampbam_open).  Record numbers of such a file count from the part's
+ * first record; header text and references are those of the whole file.  n_parts == 1 is ampbam_open. */
+int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, ampbam_file **out);
+/* Offsets in the file's INFLATED stream of the part's first record and of the byte behind its last record (equal for a
+ * part without records; 0 / 0 ... for a file opened with ampbam_open: header end / stream end are not tracked there). */
+int ampbam_part_range(const ampbam_file *f, uint64_t *first, uint64_t *end);
 void ampbam_close(ampbam_file *f);
 const char *ampbam_last_error(const ampbam_file *f);
 

@@ -85,8 +85,8 @@ def test_reencode_matches_python_writer(tmp_path):
     hdr2 = hdr.with_amplipy_pg("0.0.2", "amplipy trim")
     w = bam_native.BamWriter(out_n, hdr2.text, f, threads=2)
     half = n // 2                                                   # two calls, like two batches
-    w.write_rows(batch.src_index[:half], keep[:half], new_pos[:half], new_ncig[:half], slot_off[:half], new_cig)
-    w.write_rows(batch.src_index[half:], keep[half:], new_pos[half:], new_ncig[half:], slot_off[half:], new_cig)
+    w.write_rows(None, batch.src_index[:half], keep[:half], new_pos[:half], new_ncig[:half], slot_off[:half], new_cig)
+    w.write_rows(None, batch.src_index[half:], keep[half:], new_pos[half:], new_ncig[half:], slot_off[half:], new_cig)
     w.close()
     pw = bamio.AlignmentWriter(out_p, "wb", hdr2)
     rd = bamio.AlignmentReader(bam, "rb")
@@ -117,3 +117,42 @@ def test_bad_input_is_refused(tmp_path):
         bam_native.BamFile(p)
     with pytest.raises(bam_native.AmpBamError):
         bam_native.BamFile(str(tmp_path / "missing.bam"))
+
+
+def test_open_range_parts_tile_the_file(tmp_path):
+    """ampbam_open_range (a rank inflates only its share; a file can be read piece by piece): for several
+    numbers of parts, every part's first record starts where the part before it ended (the check that makes the heuristic
+    record-start search exact), the last part ends at the end of the inflated stream, and the decoded rows of all parts,
+    concatenated, are the rows of the whole file.  Two writers: the Python codec (records straddle BGZF blocks) and
+    libampbam's own."""
+    from amplipy_amd import bam_native, synth
+    from tools.e2e_legs import write_bam
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    hb = synth.make_amplicon_batch(g, amps, 12000, seed=5)
+    p1 = str(tmp_path / "a.bam")
+    write_bam(p1, hb, int(g.size))
+    whole = bam_native.BamFile(p1)
+    wb, _ = whole.decode(0, whole.n_records, copy=True)
+    # a second file written by libampbam itself from the first
+    p2 = str(tmp_path / "b.bam")
+    w = bam_native.BamWriter(p2, whole.header_text, whole, level=1)
+    off = wb.cig_off[:-1].copy()
+    w.write_rows(None, wb.src_index, np.ones(wb.n, np.uint8), wb.pos, np.diff(wb.cig_off.astype(np.int64)).astype(np.uint32), off, wb.cig)
+    w.close()
+    for path in (p1, p2):
+        for n_parts in (2, 3, 5, 8, 64):
+            parts = [bam_native.BamFile(path, part=k, n_parts=n_parts) for k in range(n_parts)]
+            rng = [p.part_range() for p in parts]
+            nonempty = [k for k in range(n_parts) if parts[k].n_records]
+            assert sum(p.n_records for p in parts) == whole.n_records, (path, n_parts)
+            for a, b in zip(nonempty[:-1], nonempty[1:]):
+                assert rng[a][1] == rng[b][0], (path, n_parts, a, b)
+            assert all(p.header_text == whole.header_text and p.references == whole.references for p in parts)
+            rows = [p.decode(0, p.n_records, copy=True)[0] for p in parts if p.n_records]
+            assert np.array_equal(np.concatenate([r.pos for r in rows]), wb.pos)
+            assert np.array_equal(np.concatenate([r.cig for r in rows]), wb.cig)
+            assert np.array_equal(np.concatenate([r.qual for r in rows]), wb.qual)
+            assert np.array_equal(np.concatenate([r.seq for r in rows]), wb.seq)
+            for p in parts:
+                p.close()
+    whole.close()

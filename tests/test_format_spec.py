@@ -110,7 +110,7 @@ def test_written_bam_reads_back_with_a_spec_level_parser(tmp_path, writer):
         batch, _ = f.decode(0, f.n_records, copy=True)
         import numpy as np
         out = bam_native.BamWriter(path, hdr.text, f, level=6, threads=2)
-        out.write_rows(batch.src_index, np.ones(batch.n, np.uint8), batch.pos, np.diff(batch.cig_off), batch.cig_off[:-1], batch.cig)
+        out.write_rows(None, batch.src_index, np.ones(batch.n, np.uint8), batch.pos, np.diff(batch.cig_off), batch.cig_off[:-1], batch.cig)
         out.close()
         recs = [r for r in recs if not (r.flag & 4) and r.cigar is not None]     # the rows the reference's loop keeps (A:902)
     text, refs, got = spec_parse_bam(path)

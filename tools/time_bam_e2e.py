@@ -37,7 +37,7 @@ for it in range(2):
     t0 = time.perf_counter()
     keep = (res.ref_len >= 30) & ((res.trim_flags & 3) != 0)
     slot = batch.cig_off[:-1] + np.uint64(3) * np.arange(batch.n, dtype=np.uint64)
-    wr.write_rows(batch.src_index, keep, res.new_pos, res.new_ncig, slot, res.new_cig); wr.close(); T["re-encode + deflate(level 1) + write"] = time.perf_counter() - t0
+    wr.write_rows(None, batch.src_index, keep, res.new_pos, res.new_ncig, slot, res.new_cig); wr.close(); T["re-encode + deflate(level 1) + write"] = time.perf_counter() - t0
     t0 = time.perf_counter(); r = calling.call(eng, synth.genome_string(g), cp, None); T["call"] = time.perf_counter() - t0
     src.close()
     tot = sum(T.values())
