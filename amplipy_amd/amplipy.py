@@ -474,19 +474,13 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         # before the one collective of the run: did every rank get through its share (a rank that raised must not leave the
         # others waiting in the all-reduce), and do the shares of neighbouring ranks meet (every share of a BAM file starts
         # where the one before it ended: what makes the split of ampbam_open_range exact)
-        notes = [None] * world
-        dist.all_gather_object(notes, (seam, None if rank_error is None else "%s: %s" % (type(rank_error).__name__, rank_error)))
-        errs = [e_ for _, e_ in notes if e_]
-        ends = [sm for sm, _ in notes if sm[0] is not None]
-        bad_seam = next(((x[1], y[0]) for x, y in zip(ends[:-1], ends[1:]) if x[1] != y[0]), None)
-        if errs or bad_seam:
+        trouble = parallel.exchange_notes(dist, world, seam, rank_error)
+        if trouble:
             eng.close()
             parallel.finish(dist)
             if rank_error is not None:
                 raise rank_error
-            if errs:
-                raise RuntimeError("another rank failed: %s" % errs[0])
-            raise bam_native_error("the shares of two ranks do not meet (inflated offsets %d / %d)" % bad_seam)
+            raise RuntimeError(trouble)
 
     if do_count:
         cp = calling.call_params(min_depth_consensus if min_depth_consensus is not None else 0,

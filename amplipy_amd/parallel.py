@@ -64,6 +64,23 @@ def shard_bounds_from_lseq(lseq, world):
     return cuts
 
 
+def exchange_notes(dist, world, seam, error):
+    """Before the run's one collective: did every rank get through its share (a rank that raised must not leave the others
+    waiting in the all-reduce), and do the shares of neighbouring ranks meet?  ``seam`` = [first, end) offsets of the rank's
+    share in the input's inflated stream (ampbam_open_range; [None, None] for an empty share or text input), ``error`` = the
+    exception the rank caught (or None).  Returns None when all is well, else the message every rank should fail with."""
+    notes = [None] * world
+    dist.all_gather_object(notes, (list(seam), None if error is None else "%s: %s" % (type(error).__name__, error)))
+    errs = ["rank %d: %s" % (r, e_) for r, (_, e_) in enumerate(notes) if e_]
+    if errs:
+        return "; ".join(errs)
+    ends = [sm for sm, _ in notes if sm[0] is not None]
+    for x, y in zip(ends[:-1], ends[1:]):
+        if x[1] != y[0]:
+            return "the shares of two ranks do not meet (inflated offsets %d / %d)" % (x[1], y[0])
+    return None
+
+
 def reduce_table(dist, table, dst=0):
     """Sum the device table (torch int32/uint32-as-int32 tensor) onto ``dst``."""
     dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM)

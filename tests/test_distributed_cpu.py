@@ -136,3 +136,87 @@ def test_shard_bounds_balance_bases():
         assert sum(bases) == b.total_bases()
         assert max(bases) - min(bases) <= 2 * 300      # within a couple of reads of each other
     assert parallel.amplicon_range(98, 0, 8) == (0, 12) and parallel.amplicon_range(98, 7, 8)[1] == 98
+
+
+def _worker_file_partition(rank, world, port, bam_path, out_dir, fail_rank):
+    """What run_amplipy does with a BAM file under torchrun, with the CPU oracle standing in for the GPU engine only: the
+    rank's share comes from amplipy.NativeInput (pieces of ampbam_open_range, cut by compressed bytes at BGZF block starts,
+    the next piece inflated ahead), seams and errors go through parallel.exchange_notes, ONE all-reduce stitches the tables,
+    insertion alleles travel as (position, text, count) runs through parallel.allgather_relevant_events and
+    calling.tallies_from_runs."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["AMPLIPY_PART_BYTES"] = str(96 << 10)          # several pieces per rank on a small file
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from collections import Counter
+        from amplipy_amd import amplipy, calling
+        g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+        mn, mx, mpl = oracle.find_overlapping_primers(g.size, [(s, e) for s, e, _ in primers], 0)
+        src = amplipy.NativeInput(bam_path, rank, world)
+        table = np.zeros(g.size * 7, np.int64)
+        runs = Counter()
+        n_rows = n_pieces = 0
+        err = None
+        try:
+            for piece in src:
+                n_pieces += 1
+                if piece.n_records:
+                    b, _ = piece.decode(0, piece.n_records, copy=True)
+                    r = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+                    table[:g.size * 6] += r.counts.reshape(-1)
+                    np.add.at(table[g.size * 6:], r.events["ref_pos"], 1)
+                    runs.update(event_strings(b, r.events))
+                    n_rows += b.n
+                piece.close()
+            if rank == fail_rank:
+                raise ValueError("made-up failure of one rank")
+        except Exception as e:
+            err = e
+        trouble = parallel.exchange_notes(dist, world, getattr(src, "seam", [None, None]), err)
+        if trouble:
+            with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+                f.write(trouble)
+            return
+        t = torch.from_numpy(table.astype(np.int32))
+        parallel.allreduce_table(dist, t)
+        rel = set(int(p) for p in np.nonzero(t.numpy()[g.size * 6:])[0][::53])        # same on every rank by construction
+        triples = [(p, s_, c) for (p, s_), c in runs.items() if p in rel]
+        tallies = calling.tallies_from_runs(parallel.allgather_relevant_events(dist, world, triples), rel)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), table=t.numpy(), n_rows=n_rows, n_pieces=n_pieces,
+                 tallies=np.array(sorted((p, s_, c) for p, d in tallies.items() for s_, c in d.items()), dtype=object))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_amplipys_file_partition_and_gather(tmp_path, world):
+    from collections import Counter
+    from amplipy_amd import bam_native
+    from tools.e2e_legs import write_bam
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    mn, mx, mpl = oracle.find_overlapping_primers(g.size, [(s, e) for s, e, _ in primers], 0)
+    batch = synth.make_amplicon_batch(g, amps, 9000, seed=79)
+    bam = str(tmp_path / "in.bam")
+    write_bam(bam, batch, int(g.size))
+    out = tmp_path / "ok"; out.mkdir()
+    mp.spawn(_worker_file_partition, args=(world, _free_port(), bam, str(out), -1), nprocs=world, join=True)
+    ref = oracle.process(batch, g.size, mn, mx, mpl, 20, 4)
+    tally = np.zeros(g.size, np.int64); np.add.at(tally, ref.events["ref_pos"], 1)
+    want_runs = Counter(event_strings(batch, ref.events))
+    rows = 0
+    for rank in range(world):
+        got = np.load(str(out / ("r%d.npz" % rank)), allow_pickle=True)
+        table = got["table"].view(np.uint32)
+        assert np.array_equal(table[:g.size * 6].reshape(g.size, 6), ref.counts)
+        assert np.array_equal(table[g.size * 6:], tally.astype(np.uint32))
+        rel = set(int(p) for p in np.nonzero(tally)[0][::53])
+        assert [tuple(x) for x in got["tallies"]] == sorted((p, s_, c) for (p, s_), c in want_runs.items() if p in rel)
+        assert int(got["n_pieces"]) >= 2               # the share really was walked piece by piece
+        rows += int(got["n_rows"])
+    assert rows == batch.n                             # every record belongs to exactly one rank
+    # one rank fails in front of the collective: every rank learns of it instead of waiting in the all-reduce
+    bad = tmp_path / "bad"; bad.mkdir()
+    mp.spawn(_worker_file_partition, args=(world, _free_port(), bam, str(bad), world - 1), nprocs=world, join=True)
+    for rank in range(world):
+        msg = (bad / ("r%d.txt" % rank)).read_text()
+        assert "rank %d: ValueError: made-up failure" % (world - 1) in msg
