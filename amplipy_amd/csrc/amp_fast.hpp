@@ -34,6 +34,7 @@
 #pragma once
 
 #include "amp_tile.hpp"
+#include "amp_bf.hpp"
 
 namespace amp {
 
@@ -44,6 +45,11 @@ namespace amp {
 #define AMP_F_LDSPAD 0
 #endif
 constexpr int F_WAVES = AMP_F_WAVES;  // waves per block (one block per CU: LDS)
+#ifndef AMP_F4_BF
+#define AMP_F4_BF 0      // 1: the trims of a read in their branch-free form (amp_bf.hpp, what variant 5 runs; measured: the same 0.265 ms); 0: the branchy closed forms of amp_read.hpp
+#endif
+__device__ __forceinline__ Bf bf_of(const Cig2 &s) { return Bf{s.a, s.m1, s.k, s.m2, s.c, s.kind, s.op, s.punt ? 1u : 0u}; }
+__device__ __forceinline__ Cig2 cig2_of(const Bf &b) { return Cig2{b.op, b.a, b.m1, b.k, b.m2, b.c, b.kind, b.punt != 0u}; }
 constexpr int F_NP = 10;              // 16-base pieces per read held in registers
 constexpr int F_MAXLEN = 152;         // longest read the fast path takes: F_NP pieces must cover it from 8 bases before its start
 constexpr int F_PW = 256;             // reference positions covered by a wave's packed window
@@ -423,11 +429,18 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     // reference length (A:451 looks the right table up at its last position)
     auto shape_of = [&](const HdrP &h, const Cg &c, bool fastq) {
         Shape r;
+#if AMP_F4_BF
+        bool ok;
+        r.s = cig2_of(bf_from_words5((int)h.nops(), c.w[0], c.w[1], c.w[2], c.w[3], c.w[4], (int32_t)h.lseq(), F_MAXINS, F_MAXDEL, ok));
+        r.ok = ok & fastq;
+        if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+#else
         r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
         const int nops = (int)h.nops();
         r.ok = fastq && nops >= 1 && nops <= 5 && cig2_from_words5(nops, c.w, (int32_t)h.lseq(), r.s);
         if (r.ok && ((r.s.kind == 1 && r.s.k > F_MAXINS) || (r.s.kind == 2 && r.s.k > F_MAXDEL))) r.ok = false;
         if (!r.ok) r.s = Cig2{0u, 0, 0, 0, 0, 0, 0, false};
+#endif
         r.refspan = r.ok ? r.s.m1 + r.s.m2 + (r.s.kind == 2 ? r.s.k : 0) : 1;               // (m2 = 0 without an indel; soft clips cover no reference)
         return r;
     };
@@ -580,6 +593,20 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         // no clip moves them while the indel survives
         const int32_t q_ins = s.kind ? s.a + s.m1 : 0, q_seg2 = q_ins + (s.kind == 1 ? s.k : 0);
         TrimState ts{pos, 1, 0u, 0};
+#if AMP_F4_BF
+        {
+            const bool trim = shaped & (P.do_trim != 0), use = trim & in_ref;
+            ts.err = (trim & !in_ref) ? AMP_RS_INDEX_REF : 0;
+            int32_t p2 = pos; uint32_t f2 = 0u;
+            const Bf sp = bf_trim_primers(bf_of(s), p2, f2, flag, h.isize_flag(), (int32_t)lseq, tA.L, tA.R);
+            s = cig2_of(bf_pick(use, sp, bf_of(s))); ts.pos = use ? p2 : pos; ts.flags = use ? f2 : 0u;
+        }
+        const bool scan = shaped & (P.do_trim != 0) & (ts.err == 0) & !s.punt;
+        // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
+        int32_t lo, qlen;
+        bf_quality_window(bf_of(s), (int32_t)lseq, lo, qlen);
+        lo = scan ? lo + (int32_t)phi : 0; qlen = scan ? qlen : 0;
+#else
         if (shaped && P.do_trim) {
             if (!in_ref) ts.err = AMP_RS_INDEX_REF;
             else cig2_trim_primers_isize(ts, flag, h.isize_flag(), (int32_t)lseq, s, tA.L, tA.R);
@@ -588,6 +615,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         // aligned-quality window [lo, hi) in PIECE coordinates (query index + phi)
         int32_t lo = 0, qlen = 0;
         if (scan) { cig2_quality_window(s, (int32_t)lseq, lo, qlen); lo += (int32_t)phi; }
+#endif
         const int32_t hi = lo + qlen;
         // Bytes the slots cannot give (they are rotated per lane), read from the staged qualities while they are still there:
         // the 3' end's shrinking windows (A:575-576, A:637-638) need at most W-1 bytes; reads with an indel need the
@@ -683,7 +711,11 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                             if ((int64_t)acc < (int64_t)mq * k) iq = rev ? k : qlen - k;
                         }
                     }
+#if AMP_F4_BF
+                    { uint32_t f2 = ts.flags; s = cig2_of(bf_trim_quality(bf_of(s), ts.pos, f2, rev, iq, qlen)); ts.flags = f2; }
+#else
                     cig2_trim_quality(ts, rev, iq, qlen, s);
+#endif
                 }
                 if (s.punt) {
                     general = true;
