@@ -45,6 +45,9 @@ namespace amp {
 #define AMP_F_LDSPAD 0
 #endif
 constexpr int F_WAVES = AMP_F_WAVES;  // waves per block (one block per CU: LDS)
+#ifndef AMP_F4_LEAN
+#define AMP_F4_LEAN 1    // counting from 16 good-quality bits per piece with the lean piece code below (count_piece5); 0: round 2's fast_count_piece
+#endif
 #ifndef AMP_F4_BF
 #define AMP_F4_BF 0      // 1: the trims of a read in their branch-free form (amp_bf.hpp, what variant 5 runs; measured: the same 0.265 ms); 0: the branchy closed forms of amp_read.hpp
 #endif
@@ -235,6 +238,64 @@ __device__ __forceinline__ bool fast_count_piece(const uint4 &q, const uint2 &sq
     return redo;
 }
 
+// ---- the lean piece code (shared with the second-generation kernel, amp_fast5.hpp) ------------------------------------------
+// bit 7 of every byte: quality >= mq (mq <= 128, mqb = mq in every byte); three instructions
+__device__ __forceinline__ uint32_t ok80(uint32_t q, uint32_t mqb) {
+    const uint32_t t = ((q & 0x7F7F7F7Fu) | 0x80808080u) - mqb;
+    return (t | q) & 0x80808080u;
+}
+// 16 bits "quality >= mq" of a piece
+__device__ __forceinline__ uint32_t ok_bits16(const uint4 &q, uint32_t mqb) {
+    // byte flags 0x80 times the weights 1 2 4 8 (16 32 64 128) add up to the nibble << 7
+    uint32_t lo = __builtin_amdgcn_udot4(ok80(q.x, mqb), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(ok80(q.y, mqb), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(ok80(q.z, mqb), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(ok80(q.w, mqb), 0x80402010u, hi, false);
+    return (lo >> 7) | ((hi >> 7) << 8);
+}
+// zero when all 8 nibbles of x hold exactly one bit (A C G T)
+__device__ __forceinline__ uint32_t nibbles_bad(uint32_t x, uint32_t y) {
+    const uint32_t z = ((x - 0x11111111u) & ~x & 0x88888888u) | ((y - 0x11111111u) & ~y & 0x88888888u);      // a zero nibble
+    return z | ((uint32_t)(__builtin_popcount(x) + __builtin_popcount(y)) ^ 16u);
+}
+// counter word at wb + 4 * B  +=  (byte JV of val) << (byte JS of sh)
+template <int JS, int JV, int B>
+__device__ __forceinline__ void add_base2(uint32_t wb, uint32_t sh, uint32_t val) {
+#define AMP_AB2(js, jv) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #js " src1_sel:BYTE_" #jv "\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory")
+    uint32_t t;
+    if (JS == 0 && JV == 0) AMP_AB2(0, 0); if (JS == 0 && JV == 1) AMP_AB2(0, 1); if (JS == 0 && JV == 2) AMP_AB2(0, 2); if (JS == 0 && JV == 3) AMP_AB2(0, 3);
+    if (JS == 1 && JV == 0) AMP_AB2(1, 0); if (JS == 1 && JV == 1) AMP_AB2(1, 1); if (JS == 1 && JV == 2) AMP_AB2(1, 2); if (JS == 1 && JV == 3) AMP_AB2(1, 3);
+    if (JS == 2 && JV == 0) AMP_AB2(2, 0); if (JS == 2 && JV == 1) AMP_AB2(2, 1); if (JS == 2 && JV == 2) AMP_AB2(2, 2); if (JS == 2 && JV == 3) AMP_AB2(2, 3);
+    if (JS == 3 && JV == 0) AMP_AB2(3, 0); if (JS == 3 && JV == 1) AMP_AB2(3, 1); if (JS == 3 && JV == 2) AMP_AB2(3, 2); if (JS == 3 && JV == 3) AMP_AB2(3, 3);
+#undef AMP_AB2
+}
+// One piece (16 bases): packed codes sq, counted-base bits m16 (bit b: base b of the piece is inside the counted range
+// and good enough), window offset d0 of its base 0, against the lane's replica of the wave's packed window.
+// Returns true when the careful loop has to redo the piece (a code outside A C G T in it, or it leaves the window).
+__device__ __forceinline__ uint32_t count_piece5(const uint2 &sq, uint32_t m16, int32_t d0, int32_t lim16, uint32_t wrep) {
+    // (bit operations on purpose: with && / || the compiler branches around the tests)
+    const bool inwin = (d0 >= 0) & (d0 <= lim16);                       // lim16 = the window's width - 16 (negative: nothing fits)
+    const bool redo = (m16 != 0u) & (!inwin | (nibbles_bad(sq.x, sq.y) != 0u));
+    const uint32_t m = redo ? 0u : m16;
+    // shift counts of the even / odd bases of each half (the high nibble of a byte is the even base)
+    const uint32_t se0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.x >> 4) & 0x07070707u);
+    const uint32_t so0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.x & 0x07070707u);
+    const uint32_t se1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.y >> 4) & 0x07070707u);
+    const uint32_t so1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.y & 0x07070707u);
+    const uint32_t f0 = nibble_to_bytes(m, 0), f1 = nibble_to_bytes(m, 1), f2 = nibble_to_bytes(m, 2), f3 = nibble_to_bytes(m, 3);
+    const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u : 0u);
+    add_base2<0, 0, 0>(wb, se0, f0);   add_base2<0, 1, 1>(wb, so0, f0);   add_base2<1, 2, 2>(wb, se0, f0);   add_base2<1, 3, 3>(wb, so0, f0);
+    add_base2<2, 0, 4>(wb, se0, f1);   add_base2<2, 1, 5>(wb, so0, f1);   add_base2<3, 2, 6>(wb, se0, f1);   add_base2<3, 3, 7>(wb, so0, f1);
+    add_base2<0, 0, 8>(wb, se1, f2);   add_base2<0, 1, 9>(wb, so1, f2);   add_base2<1, 2, 10>(wb, se1, f2);  add_base2<1, 3, 11>(wb, so1, f2);
+    add_base2<2, 0, 12>(wb, se1, f3);  add_base2<2, 1, 13>(wb, so1, f3);  add_base2<3, 2, 14>(wb, se1, f3);  add_base2<3, 3, 15>(wb, so1, f3);
+    return redo ? 1u : 0u;
+}
+// bits [klo, khi) of a 16-bit mask, klo / khi clamped to 0..16
+__device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
+    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
+    return ((1u << khi) - 1u) & ~((1u << klo) - 1u);                    // empty when khi <= klo
+}
+
 // in-kernel phase stamps (development builds only; the numbers are shares, not durations); AMP_ABL = ablation
 // builds (parts of the kernel switched off to time the rest: results are wrong on purpose), without stamps
 #if defined(AMP_DEV) && (!defined(AMP_ABL) || defined(AMP_ABL_STAMPS))
@@ -287,6 +348,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     lds_u32 *const pwin = (lds_u32 *)s_pwin[wave];
     for (int i = tid; i < F_BPL * F_BW; i += F_WAVES * 64) bwin[i] = 0;
     for (int i = lane; i < F_REP * F_REPW; i += 64) pwin[i] = 0;
+    if (lane < F_PAD / 4) ((lds_u32 *)s_stage[wave])[lane] = 0x11111111u;      // (the bytes in front of a staged run are read as bases by the lanes whose pieces start 8 bases early)
     if (tid == 0) { s_ticket = 0; s_gcur = 0; }
     if (tid == 0 && blockIdx.x == 0) { eb.ctr[26] = 0ull; eb.ctr[27] = 0ull; eb.ctr[28] = 0ull; }      // k_gcompact / k_long's counters (amp_wave.hpp)
     // the block's window: anchored 16 positions left of its first read (sorted input: nothing of this block starts
@@ -630,6 +692,23 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
 #pragma unroll
         for (int sl = 0; sl < F_STAGE / 2048; ++sl) *(lds_u32x4 *)(stage + sl * 1024 + lane * 16) = amp_u32x4{xA.raws[sl].x, xA.raws[sl].y, xA.raws[sl].z, xA.raws[sl].w};
         wave_sync();
+#if AMP_F4_LEAN
+        {
+            // the test for codes outside A C G T looks at whole pieces (nibbles_bad): pad nibbles of the staged rows (a row is
+            // padded to 8 bases) and the 16 bytes behind the run become a valid code
+            if (lane == 0) *(lds_u32x4 *)(stage + ((g.Tq >> 1) & ~3u)) = amp_u32x4{0x11111111u, 0x11111111u, 0x11111111u, 0x11111111u};
+            wave_sync();
+            const uint32_t e = fastq ? lseq & 7u : 0u;                        // bases of the row's last group of 8 (0: the group is full)
+            if (e) {
+                lds_u32 *w = (lds_u32 *)(stage + (g.row >> 1) + 4u * (lseq >> 3));
+                const uint32_t x = *w, xs = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);      // nibble i at bit 4 i
+                const uint32_t keepn = (1u << (4u * e)) - 1u;
+                const uint32_t ys = (xs & keepn) | (0x11111111u & ~keepn);
+                *w = ((ys & 0x0F0F0F0Fu) << 4) | ((ys >> 4) & 0x0F0F0F0Fu);
+            }
+            wave_sync();
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < F_NP; ++k) {
             uint32_t p = (uint32_t)k + rot;
@@ -817,6 +896,12 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             }
         }
         uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F_NP = group B
+#if AMP_F4_LEAN
+        uint32_t okm[F_NP];                       // 16 good-quality bits per piece: the qualities are done with
+#pragma unroll
+        for (int k = 0; k < F_NP; ++k) okm[k] = ok_bits16(q16[k], mqb);
+        const uint32_t okB = ok_bits16(make_uint4(bq0.x, bq0.y, bq1.x, bq1.y), mqb);
+#endif
         // group B: the part of the second segment that shares a piece with the first
         int32_t xbe = 0, jb = 0;
         bool has_b = false;
@@ -852,9 +937,17 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
             const bool now = todo && (fits || lane == lead);
             const int32_t a1 = now ? qa1 : 0, b1 = now ? qb1 : 0, a2 = now ? qa2 : 0, b2 = now ? qb2 : 0;
             const int32_t dbase1 = ts.pos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
+#if AMP_F4_LEAN
+            const int32_t lim16 = (int32_t)pw_lim - 16;
+            if (__ballot(has_b && now)) {
+                const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
+                redo |= count_piece5(bsq, mB, dbase2 + jb, lim16, (uint32_t)(uintptr_t)wrep) << F_NP;
+            }
+#else
             if (__ballot(has_b && now)) {
                 if (has_b && now && count_piece(make_uint4(bq0.x, bq0.y, bq1.x, bq1.y), bsq, jb, qa2, xbe, dbase2)) redo |= 1u << F_NP;
             }
+#endif
 #pragma unroll
             for (int k = 0; k < F_NP; ++k) {
                 uint32_t p = (uint32_t)k + rot;
@@ -864,9 +957,14 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
                 // (the empty asm keeps the compiler from computing the pass-independent half of every piece in front of
                 // the pass loop, which costs eighty registers this kernel does not have)
+#if AMP_F4_LEAN
+                redo |= count_piece5(s8[k], okm[k] & range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0), (second ? dbase2 : dbase1) + j0, lim16,
+                                     (uint32_t)(uintptr_t)wrep) << k;
+#else
                 asm volatile("" : "+v"(q16[k].x), "+v"(q16[k].y), "+v"(q16[k].z), "+v"(q16[k].w), "+v"(s8[k].x), "+v"(s8[k].y));
                 if (count_piece(q16[k], s8[k], j0, second ? a2 : a1, second ? b2 : b1, second ? dbase2 : dbase1)) redo |= 1u << k;
                 __builtin_amdgcn_sched_barrier(0);          // one piece at a time: interleaving them costs registers the kernel does not have
+#endif
             }
             todo = todo && !now;
         }

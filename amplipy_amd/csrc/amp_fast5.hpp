@@ -48,68 +48,12 @@ constexpr int F5_PAD = 16;                // bytes in front of / behind a staged
 // (Four replicas instead of variant 4's eight: two-way bank conflicts cost nothing, the LDS takes four cycles to receive an
 // atomic's operands anyway.)
 
-// bit 7 of every byte: quality >= mq (mq <= 128, mqb = mq in every byte); three instructions
-__device__ __forceinline__ uint32_t ok80(uint32_t q, uint32_t mqb) {
-    const uint32_t t = ((q & 0x7F7F7F7Fu) | 0x80808080u) - mqb;
-    return (t | q) & 0x80808080u;
-}
-// 16 bits "quality >= mq" of a piece
-__device__ __forceinline__ uint32_t ok_bits16(const uint4 &q, uint32_t mqb) {
-    // byte flags 0x80 times the weights 1 2 4 8 (16 32 64 128) add up to the nibble << 7
-    uint32_t lo = __builtin_amdgcn_udot4(ok80(q.x, mqb), 0x08040201u, 0u, false);
-    lo = __builtin_amdgcn_udot4(ok80(q.y, mqb), 0x80402010u, lo, false);
-    uint32_t hi = __builtin_amdgcn_udot4(ok80(q.z, mqb), 0x08040201u, 0u, false);
-    hi = __builtin_amdgcn_udot4(ok80(q.w, mqb), 0x80402010u, hi, false);
-    return (lo >> 7) | ((hi >> 7) << 8);
-}
-// zero when all 8 nibbles of x hold exactly one bit (A C G T)
-__device__ __forceinline__ uint32_t nibbles_bad(uint32_t x, uint32_t y) {
-    const uint32_t z = ((x - 0x11111111u) & ~x & 0x88888888u) | ((y - 0x11111111u) & ~y & 0x88888888u);      // a zero nibble
-    return z | ((uint32_t)(__builtin_popcount(x) + __builtin_popcount(y)) ^ 16u);
-}
-// counter word at wb + 4 * B  +=  (byte JV of val) << (byte JS of sh)
-template <int JS, int JV, int B>
-__device__ __forceinline__ void add_base2(uint32_t wb, uint32_t sh, uint32_t val) {
-#define AMP_AB2(js, jv) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #js " src1_sel:BYTE_" #jv "\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(val), "v"(wb), "n"(4 * B) : "memory")
-    uint32_t t;
-    if (JS == 0 && JV == 0) AMP_AB2(0, 0); if (JS == 0 && JV == 1) AMP_AB2(0, 1); if (JS == 0 && JV == 2) AMP_AB2(0, 2); if (JS == 0 && JV == 3) AMP_AB2(0, 3);
-    if (JS == 1 && JV == 0) AMP_AB2(1, 0); if (JS == 1 && JV == 1) AMP_AB2(1, 1); if (JS == 1 && JV == 2) AMP_AB2(1, 2); if (JS == 1 && JV == 3) AMP_AB2(1, 3);
-    if (JS == 2 && JV == 0) AMP_AB2(2, 0); if (JS == 2 && JV == 1) AMP_AB2(2, 1); if (JS == 2 && JV == 2) AMP_AB2(2, 2); if (JS == 2 && JV == 3) AMP_AB2(2, 3);
-    if (JS == 3 && JV == 0) AMP_AB2(3, 0); if (JS == 3 && JV == 1) AMP_AB2(3, 1); if (JS == 3 && JV == 2) AMP_AB2(3, 2); if (JS == 3 && JV == 3) AMP_AB2(3, 3);
-#undef AMP_AB2
-}
 // LDS-DMA of 16 bytes per lane, issued where the compiler cannot see it (see the head of the file)
 __device__ __forceinline__ void dma16(const void *g, const lds_u8 *l) {
     const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)l);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
 }
 
-// One piece (16 bases): packed codes sq, counted-base bits m16 (bit b: base b of the piece is inside the counted range
-// and good enough), window offset d0 of its base 0, against the lane's replica of the wave's packed window.
-// Returns true when the careful loop has to redo the piece (a code outside A C G T in it, or it leaves the window).
-__device__ __forceinline__ uint32_t count_piece5(const uint2 &sq, uint32_t m16, int32_t d0, int32_t lim16, uint32_t wrep) {
-    // (bit operations on purpose: with && / || the compiler branches around the tests)
-    const bool inwin = (d0 >= 0) & (d0 <= lim16);                       // lim16 = the window's width - 16 (negative: nothing fits)
-    const bool redo = (m16 != 0u) & (!inwin | (nibbles_bad(sq.x, sq.y) != 0u));
-    const uint32_t m = redo ? 0u : m16;
-    // shift counts of the even / odd bases of each half (the high nibble of a byte is the even base)
-    const uint32_t se0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.x >> 4) & 0x07070707u);
-    const uint32_t so0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.x & 0x07070707u);
-    const uint32_t se1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.y >> 4) & 0x07070707u);
-    const uint32_t so1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.y & 0x07070707u);
-    const uint32_t f0 = nibble_to_bytes(m, 0), f1 = nibble_to_bytes(m, 1), f2 = nibble_to_bytes(m, 2), f3 = nibble_to_bytes(m, 3);
-    const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u : 0u);
-    add_base2<0, 0, 0>(wb, se0, f0);   add_base2<0, 1, 1>(wb, so0, f0);   add_base2<1, 2, 2>(wb, se0, f0);   add_base2<1, 3, 3>(wb, so0, f0);
-    add_base2<2, 0, 4>(wb, se0, f1);   add_base2<2, 1, 5>(wb, so0, f1);   add_base2<3, 2, 6>(wb, se0, f1);   add_base2<3, 3, 7>(wb, so0, f1);
-    add_base2<0, 0, 8>(wb, se1, f2);   add_base2<0, 1, 9>(wb, so1, f2);   add_base2<1, 2, 10>(wb, se1, f2);  add_base2<1, 3, 11>(wb, so1, f2);
-    add_base2<2, 0, 12>(wb, se1, f3);  add_base2<2, 1, 13>(wb, so1, f3);  add_base2<3, 2, 14>(wb, se1, f3);  add_base2<3, 3, 15>(wb, so1, f3);
-    return redo ? 1u : 0u;
-}
-// bits [klo, khi) of a 16-bit mask, klo / khi clamped to 0..16
-__device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
-    klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
-    return ((1u << khi) - 1u) & ~((1u << klo) - 1u);                    // empty when khi <= klo
-}
 // OR over the lanes of the wave (DPP row shifts and row broadcasts; the result is uniform)
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
     uint32_t t = x;
