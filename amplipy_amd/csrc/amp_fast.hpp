@@ -49,7 +49,7 @@ constexpr int F_WAVES = AMP_F_WAVES;  // waves per block (one block per CU: LDS)
 #define AMP_F4_LEAN 1    // counting from 16 good-quality bits per piece with the lean piece code below (count_piece5); 0: round 2's fast_count_piece
 #endif
 #ifndef AMP_F4_BF
-#define AMP_F4_BF 0      // 1: the trims of a read in their branch-free form (amp_bf.hpp, what variant 5 runs; measured: the same 0.265 ms); 0: the branchy closed forms of amp_read.hpp
+#define AMP_F4_BF 1      // 1: the trims of a read in their branch-free form (amp_bf.hpp, fuzzed against the branchy forms on the CPU; 1 % faster); 0: the branchy closed forms of amp_read.hpp
 #endif
 __device__ __forceinline__ Bf bf_of(const Cig2 &s) { return Bf{s.a, s.m1, s.k, s.m2, s.c, s.kind, s.op, s.punt ? 1u : 0u}; }
 __device__ __forceinline__ Cig2 cig2_of(const Bf &b) { return Cig2{b.op, b.a, b.m1, b.k, b.m2, b.c, b.kind, b.punt != 0u}; }
