@@ -66,11 +66,12 @@ def main():
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4: one job of --depth partitioned over the ranks (strong scaling)")
     ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = chosen per batch by the library)")
-    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: two steps in flight)")
-    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (each has its own stream, engine and outputs)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: four steps in flight over four streams)")
+    ap.add_argument("--in-flight", type=int, default=4, help="steps in flight (each has its own engine, table and outputs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs behind the timed region (config 3: 100k x depth; config 5: 8.0 M mixed reads)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps in flight are dealt over (1: the GPU runs step after step; 2+: the next step's reads start on the CUs the last blocks of this step's reads have left)")
     ap.add_argument("--no-comm-overlap", action="store_true", help="multi-rank runs: all-reduce on the work stream, in front of the step's calls (default: on its own stream, under the next step's reads)")
     args = ap.parse_args()
 
@@ -116,10 +117,14 @@ def main():
     rd = batch.struct()
     cp = calling.call_params(10, 0.0, 1, 0.03, True, True)
 
-    # ONE HIP stream for the GPU work of every step: the GPU runs reads(k), calls(k), reads(k+1), ... strictly in that
-    # order (with a stream per step the small calling kernels of step k had to wait for a CU behind the blocks of the
-    # next step's reads, which fill every CU), and the host assembles step k's records while reads(k+1) run
-    work_stream = torch.cuda.Stream(device=dev)
+    # The steps in flight are dealt over a few HIP streams (each step has its own engine, table and outputs).  The scan pass is
+    # one block per CU for its whole duration, so on ONE stream the chip idles through every pass's last tile and through the
+    # small calling kernels behind it (0.264 ms per step for a 0.234 ms pass); with the next step on another stream its blocks
+    # take the CUs as they come free and the small kernels (reset 8, calls 40 / 32 VGPRs, no LDS to speak of) run beside them:
+    # 0.2405 ms with four steps over four streams.  Two steps in flight are not enough for this: the calls of step k then sit
+    # behind the blocks of reads(k+1) while the host waits for them with nothing else queued.
+    work_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    work_stream = work_streams[0]
     # multi-rank runs: the step's one collective goes to a stream of its own.  xGMI moves the 0.8 MB table while the work
     # stream already runs the next step's reads (other slot, other table); the step's calls are queued behind those reads
     # and wait for the reduced table through an event.  One step of latency, no idle GPU around the collective.
@@ -128,8 +133,8 @@ def main():
     class Slot:
         """One in-flight step: its own engine (device table, event list, scratch, pinned result image) and outputs."""
 
-        def __init__(self, b=batch):
-            self.stream = work_stream
+        def __init__(self, b=batch, lane=0):
+            self.stream = work_streams[lane % len(work_streams)]
             self.eng = eng = lib.Engine(G, device=local_rank)
             eng.set_kernel_variant(args.variant)
             eng.set_stream(self.stream.cuda_stream)
@@ -169,7 +174,7 @@ def main():
     depth = 1 if args.no_pipeline else max(1, args.in_flight)
     if comm_stream is not None:
         depth += 1        # the calls of a step are queued one step later: one more step in flight keeps the host's record assembly under the GPU's work
-    slots = [Slot() for _ in range(depth)]
+    slots = [Slot(lane=k) for k in range(depth)]
     pass_ms, fast_ms = [], []
     last = {}
 
@@ -265,6 +270,8 @@ def main():
     alg_bytes = n_reads * (16 + (L + 1) // 2 + L + 8) + 4 * n_cig_in + 4 * n_out + 6 * G * 4 + 2 * G * 4
     k_ms = float(np.mean(pass_ms))
     k_solo = float(np.mean(solo_pass))
+    # one stream: the pass's own HIP-event duration inside the timed region; several: the region's pass rate (see roofline.note)
+    k_rate_ms = k_ms if len(work_streams) == 1 else elapsed / args.steps * 1e3
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.isfile(tf):
@@ -432,20 +439,28 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
                        "parallelism": "coordinate-range partition x%d + one RCCL all-reduce of the count table per step" % world,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
-                       "steps_in_flight": depth, "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
+                       "steps_in_flight": depth, "work_streams": len(work_streams), "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
                        "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant,
                        "strong_check": strong_check},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
-                         "achieved": round(alg_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 5),
+                         "achieved": round(alg_bytes / (k_rate_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_bytes / (k_rate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_rate_ms, 5),
+                         "kernel_ms_event_span": round(k_ms, 5),
                          "kernel_ms_alone": round(k_solo, 5),
                          "frac_alone": round(alg_bytes / k_solo / 1e6 / HBM_PEAK_GBS, 5),
                          "fast_kernel_ms_alone": round(float(np.mean(solo_fast)), 5),
-                         "note": "kernel_ms / achieved / frac: HIP events around ALL kernels of the scan pass (amp_process_batch_device) "
-                                 "inside the timed region, where two steps in flight overlap each other; kernel_ms_alone / frac_alone: "
-                                 "the same launches with the GPU to itself (5 passes after the timed region); fast_kernel_ms_alone: "
-                                 "the first kernel of the pass alone (k_fast for variant 4)"},
+                         "note": ("kernel_ms / achieved / frac: the timed region deals its steps over %d HIP streams, so the scan passes of "
+                                  "consecutive steps overlap (the next one starts on the CUs the last blocks of this one have left) and "
+                                  "the HIP-event span of one pass (kernel_ms_event_span) covers time it shares with its neighbours; the "
+                                  "pass's rate inside the region is one pass per ms_per_step, which is what kernel_ms is here (an upper "
+                                  "bound of its duration: the step's calling kernels are inside it). " % len(work_streams)
+                                  if len(work_streams) > 1 else
+                                  "kernel_ms / achieved / frac: HIP events around ALL kernels of the scan pass (amp_process_batch_device) "
+                                  "inside the timed region, on the one work stream. ")
+                                 + "kernel_ms_alone / frac_alone: the same launches with the GPU to itself (5 passes after the timed "
+                                   "region, HIP events on the engine's stream; profiles/ hold the rocprofv3 kernel trace of this leg); "
+                                   "fast_kernel_ms_alone: the first kernel of the pass alone (k_fast for variant 4)"},
             "cpu_baseline": cpu,
             "e2e": e2e,
             "extra": extra,
