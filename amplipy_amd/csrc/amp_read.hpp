@@ -841,6 +841,81 @@ AMP_HD int count_read_walk(const KParams &P, const CB &cig, int n, int32_t ref_s
     return 0;
 }
 
+// The indel effects of count_read_walk op by op, without the pair iterator (one step per BASE of every op there; here a step per op, a short loop
+// over the bases of a deletion and over the bases of an insertion run): what the in-tile walk of k_tile runs.  A literal
+// restatement of A:714-748 on a regular CIGAR -- the pairs of an insertion are (q, None), the run of good-quality bases
+// from its first one ends at a low base or at the alignment end (the event is then counted at reference_end - 1 and that
+// pair is swallowed), or at the pair behind the insertion: a match base (anchored there; the r == 0 quirk of A:735), a
+// deleted base (q is None: the allele is SEQ[q0 - 1:]), a clipped base at the alignment end (counted at reference_end - 1)
+// or nothing at all (A:734 raises).  I ops that follow each other are one run (zero-length ops and hard clips have no pairs).
+template <class CB, class Sink, class QF>
+AMP_HD int count_regular_ops(const KParams &P, const CB &cig, int n, int32_t ref_start, int32_t ref_end, int32_t lseq,
+                                 int32_t qs, int32_t qe, const QF &qual, Sink &sink) {
+    const uint32_t G = (uint32_t)P.ref_len;
+    const int32_t mq = P.min_quality;
+    int32_t q = 0, r = ref_start;
+    int k = 0;
+    while (k < n) {
+        const uint32_t v = cig.get(k), op = v & 15u;
+        const int32_t len = (int32_t)(v >> 4);
+        ++k;
+        if (is_match_op(op)) { q += len; r += len; continue; }
+        if (op == OP_S) { q += len; continue; }
+        if (op == OP_D || op == OP_N) {
+            for (int32_t j = 0; j < len; ++j, ++r) {
+                if ((uint32_t)r >= G) return AMP_RS_INDEX_REF;
+                sink.add(r, 5u);
+            }
+            continue;
+        }
+        if (op != OP_I) continue;                     // hard clips
+        int32_t L = len;
+        uint32_t nop = OP_H;                          // the op whose first pair follows the run (OP_H: none)
+        while (k < n) {
+            const uint32_t w = cig.get(k), o2 = w & 15u;
+            const int32_t l2 = (int32_t)(w >> 4);
+            if (o2 == OP_H || l2 == 0) { ++k; continue; }
+            if (o2 == OP_I) { L += l2; ++k; continue; }
+            nop = o2;
+            break;
+        }
+        const int32_t qi = q;
+        q += L;
+        int32_t j = 0;
+        while (j < L) {
+            if ((int32_t)qual(qi + j) < mq) { ++j; continue; }                             // A:718
+            if (qi + j < qs) { ++j; continue; }                                            // A:722
+            if (qi + j >= qe) return 0;                                                    // A:726
+            const int32_t js = j;
+            ++j;                                                                           // A:734: the next pair
+            while (j < L && qi + j < qe && (int32_t)qual(qi + j) >= mq) ++j;
+            int32_t lo, hi, ins_pos;
+            if (j < L) {                              // cut short inside the run; that pair is swallowed
+                py_slice(qi + js - 1, qi + j, lseq, lo, hi);                               // A:738
+                ins_pos = ref_end; ++j;                                                    // A:739-740
+            } else if (nop == OP_H) {
+                return AMP_RS_INDEX_PAIRS;                                                 // A:734
+            } else if (is_match_op(nop)) {
+                if (r == 0) py_slice(qi + js, qi + L + 1, lseq, lo, hi);                   // A:735-736
+                else py_slice(qi + js - 1, qi + L, lseq, lo, hi);                          // A:738
+                ins_pos = r;                                                               // A:742
+            } else if (nop == OP_D || nop == OP_N) {
+                if (r == 0) return AMP_RS_TYPE;
+                py_slice(qi + js - 1, lseq, lseq, lo, hi);                                 // seq[a:None]
+                ins_pos = r;
+            } else {                                  // a clipped base: of a regular read it sits at the alignment end
+                if (qi + L < qe) return AMP_RS_INDEX_PAIRS;       // (not a regular read: the exact walk of the second pass decides)
+                py_slice(qi + js - 1, qi + L, lseq, lo, hi);
+                ins_pos = ref_end;
+            }
+            ins_pos = ins_pos - 1 > 0 ? ins_pos - 1 : 0;                                   // A:744
+            if ((uint32_t)ins_pos >= G) return AMP_RS_INDEX_REF;
+            sink.event(ins_pos, lo, hi);
+        }
+    }
+    return 0;
+}
+
 // update_base_counts (A:690-753) for the shape, part 1: the effects of its indel.  A deletion counts '-' at each of
 // its positions (A:714-715).  An insertion gives one event per maximal run of good-quality inserted bases
 // (A:730-748): a run that reaches the insertion's end is anchored on the base before

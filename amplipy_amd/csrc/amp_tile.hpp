@@ -218,6 +218,9 @@ struct QualAt {
     mutable int32_t blk = -1;
     mutable uint32_t lo = 0, hi = 0;
     __device__ uint32_t operator()(int32_t k) const {
+#ifdef AMP_ABL_QUALCONST
+        return 40u;
+#endif
         if ((k >> 3) != blk) {
             blk = k >> 3;
             const uint2 v = *(const uint2 *)(q + (int64_t)blk * 8);
@@ -839,7 +842,11 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
         // is counted in several passes (a read that did not fit used to go to the second pass, whole: on a list of
         // indel-heavy reads that was one read in twenty-five, and the second pass took as long as this kernel)
         if (counted && nseg > T_SEGCAP) { counted = false; defer_full = true; nseg = 0; }      // (one read alone overflows it)
+#ifdef AMP_ABL_NOWALK
+        const bool defer_indels = false;
+#else
         const bool defer_indels = counted && !plain;   // deletions and insertion events: the in-tile walk below
+#endif
         bool seg_todo = counted;
         for (;;) {
             uint32_t total_seg;
@@ -911,7 +918,7 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
                 TileEvSink sink{tc, (uint32_t)(read_base + (uint64_t)i), seg, evcur};
                 int e1 = 0, e2 = 0;
                 const int32_t qs2 = query_alignment_start(cur, ts.n, lseq, e1), qe2 = query_alignment_end(cur, ts.n, lseq, e2);
-                indel_err = count_regular_skip(P, cur, ts.n, ts.pos, lseq, qs2, qe2, QualAt{qual}, sink) != 0;   // exact status: second pass
+                indel_err = count_regular_ops(P, cur, ts.n, ts.pos, ts.pos + reference_length(cur, ts.n), lseq, qs2, qe2, QualAt{qual}, sink) != 0;   // exact status: second pass
             }
             wave_sync();
             const uint32_t nev_all = *evcur;

@@ -45,3 +45,12 @@ def bf_fuzz(seed, iters):
     np_, nc = C.c_long(0), C.c_long(0)
     bad = L.sim_bf_fuzz(C.c_uint64(seed), C.c_long(iters), C.byref(np_), C.byref(nc))
     return int(bad), int(np_.value), int(nc.value)
+
+
+def regops_fuzz(seed, iters):
+    """(mismatches, events, error reads) of the op-by-op indel walk (count_regular_ops) against the exact pair walk."""
+    L = lib()
+    L.sim_regops_fuzz.restype = C.c_long
+    ne, nr = C.c_long(0), C.c_long(0)
+    bad = L.sim_regops_fuzz(C.c_uint64(seed), C.c_long(iters), C.byref(ne), C.byref(nr))
+    return int(bad), int(ne.value), int(nr.value)

@@ -255,3 +255,73 @@ extern "C" long sim_bf_fuzz(uint64_t seed, long iters, long *n_punt, long *n_cmp
     }
     return bad;
 }
+
+
+// ---- fuzz of the op-by-op indel walk (count_regular_ops, what the tile kernel's lanes run) against the exact pair walk
+// (count_read_walk) on random REGULAR CIGARs: H* S* (M|=|X|I|D|N)* S* H*, zero-length ops, insertions next to each other,
+// next to deletions, at either end of the body, at reference position 0 and hanging over the reference's end; qualities
+// with low bases inside the insertions.  The '-' counts, the events (position and slice) in order and the error / no error
+// outcome must be the same. -------------------------------------------------------------------------------------------
+struct RecSink {
+    std::vector<int32_t> *v;
+    void add(int32_t r, uint32_t col) { if (col == 5u) { v->push_back(-1); v->push_back(r); } }
+    void event(int32_t pos, int32_t lo, int32_t hi) { v->push_back(pos); v->push_back(lo); v->push_back(hi); }
+};
+struct QualVec {
+    const uint8_t *q;
+    uint32_t operator()(int32_t k) const { return q[k]; }
+};
+struct BytesVec {
+    const uint8_t *q;
+    uint32_t qual(int32_t i) { return q[i]; }
+    uint32_t code(int32_t) { return 1u; }
+};
+
+extern "C" long sim_regops_fuzz(uint64_t seed, long iters, long *n_events, long *n_errors) {
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 4242;
+    long bad = 0; *n_events = 0; *n_errors = 0;
+    const int32_t G = 600;
+    KParams P{20, 4, 1, 1, G, 0, nullptr, nullptr};
+    std::vector<uint32_t> cig;
+    std::vector<uint8_t> qual;
+    std::vector<int32_t> e1, e2;
+    for (long it = 0; it < iters; ++it) {
+        cig.clear();
+        if (rnd() % 8 == 0) cig.push_back(((uint32_t)rin(0, 5) << 4) | OP_H);
+        if (rnd() % 3 == 0) cig.push_back(((uint32_t)rin(0, 20) << 4) | OP_S);
+        const int nbody = rin(1, 9);
+        int32_t qlen = 0, rlen = 0;
+        for (int k = 0; k < nbody; ++k) {
+            const int t = (int)(rnd() % 10);
+            uint32_t op = t < 4 ? OP_M : t < 6 ? OP_I : t < 8 ? OP_D : t == 8 ? OP_N : (rnd() & 1u ? OP_EQ : OP_X);
+            int32_t len = rnd() % 12 == 0 ? 0 : rin(1, 14);
+            cig.push_back(((uint32_t)len << 4) | op);
+        }
+        if (rnd() % 3 == 0) cig.push_back(((uint32_t)rin(0, 20) << 4) | OP_S);
+        if (rnd() % 8 == 0) cig.push_back(((uint32_t)rin(0, 5) << 4) | OP_H);
+        for (uint32_t v : cig) { const uint32_t op = v & 15u; if (consumes_query(op)) qlen += (int32_t)(v >> 4); if (consumes_ref(op)) rlen += (int32_t)(v >> 4); }
+        if (qlen == 0) continue;
+        const int n = (int)cig.size();
+        const int32_t lseq = qlen;
+        qual.resize((size_t)lseq);
+        const int lowp = (int)(rnd() % 3);          // no / some / many low bases
+        for (int32_t i = 0; i < lseq; ++i) qual[(size_t)i] = (uint8_t)((lowp && (int)(rnd() % (lowp == 1 ? 8 : 2)) == 0) ? rin(0, 19) : rin(20, 40));
+        int32_t pos = rnd() % 4 == 0 ? 0 : rin(0, G - 1);
+        const bool inside = pos + rlen <= G;
+        if (!inside && rnd() % 4) pos = rin(0, G - rlen > 0 ? G - rlen : 0);
+        const bool in2 = pos + (rlen ? rlen : 1) <= G;
+        CigBuf<1> cb{cig.data()};
+        int er = 0;
+        const int32_t qs = query_alignment_start(cb, n, lseq, er), qe = query_alignment_end(cb, n, lseq, er);
+        if (er) continue;
+        e1.clear(); e2.clear();
+        RecSink s1{&e1}, s2{&e2};
+        const int rc1 = count_read_walk(P, cb, n, pos, lseq, BytesVec{qual.data()}, true, s1);
+        const int rc2 = count_regular_ops(P, cb, n, pos, pos + reference_length(cb, n), lseq, qs, qe, QualVec{qual.data()}, s2);
+        *n_events += (long)e2.size() / 3;
+        if (rc1) ++*n_errors;
+        if (e1 != e2) { ++bad; continue; }
+        if (in2 && (rc1 != 0) != (rc2 != 0)) ++bad;
+    }
+    return bad;
+}

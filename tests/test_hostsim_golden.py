@@ -127,3 +127,15 @@ def test_branch_free_closed_forms():
         bad, punted, compared = hostsim.bf_fuzz(seed, 150000)
         assert bad == 0, (seed, bad)
         assert compared > 1000000
+
+
+def test_op_by_op_indel_walk():
+    """count_regular_ops (amp_read.hpp: deletions and insertion events of a regular CIGAR op by op, what the tile kernel's
+    lanes run) against the exact pair walk count_read_walk on random regular CIGARs -- zero-length ops, insertions next to
+    each other, next to deletions and clips, at reference position 0, over the reference's end, low bases inside the
+    insertions: the same '-' counts, the same events in the same order, the same error / no error outcome."""
+    from tests import hostsim
+    for seed in (31, 32):
+        bad, effects, errors = hostsim.regops_fuzz(seed, 200000)
+        assert bad == 0, (seed, bad)
+        assert effects > 1000000 and errors > 10000
