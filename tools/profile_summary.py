@@ -37,7 +37,8 @@ for mode in ("pipelined", "serial"):
             acc[short(n)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     kern[mode] = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2), "min_us": round(min(v), 2), "max_us": round(max(v), 2)}
                   for k, v in acc.items()}
-kern["_note"] = ("kernel durations from rocprofv3 --kernel-trace of `bench.py` (pipelined: the default run; serial: --no-pipeline), "
+kern["_note"] = ("kernel durations from rocprofv3 --kernel-trace of `bench.py` (pipelined: the default run, steps dealt over several HIP streams, so "
+                 "kernels of consecutive steps overlap and their own durations stretch; serial: --no-pipeline, one step at a time), "
                  "launches of the bench workload only (k_fast with its full grid and the kernels behind it)")
 json.dump(kern, open(os.path.join("profiles", name + "_kernels.json"), "w"), indent=1)
 
@@ -60,7 +61,9 @@ for k, d in pmc.items():
     out[k] = o
 out["_note"] = ("means per launch over the full-size launches of `bench.py --no-pipeline` (separate --pmc passes); SQ_* cycle counters "
                 "count in units of 4 cycles; hbm_bytes_per_launch = FETCH_SIZE [KiB] * 1024 * 2 + WRITE_SIZE [KiB] * 1024 (gfx950 reports "
-                "half of the fetched bytes: *_fetch_calibration.json); reads served by the 256 MB Infinity Cache are not in FETCH_SIZE")
+                "half of the fetched bytes: *_fetch_calibration.json).  FETCH_SIZE / WRITE_SIZE come from the L2's memory-side request counters; by "
+                "/opt/skills/guides/MI355X_MICROARCH.md requests that hit the 256 MB Infinity Cache appear to be counted too, so the figure "
+                "is an upper bound of the bytes HBM itself moved")
 json.dump(out, open(os.path.join("profiles", name + "_pmc.json"), "w"), indent=1)
 
 cal = {}
