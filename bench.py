@@ -371,7 +371,7 @@ def main():
                 fraction; asserts count table, trimmed positions and event count against the sharded oracle."""
                 sl = Slot(db)
                 ms = []
-                for it in range(4):
+                for it in range(14):
                     with torch.cuda.stream(sl.stream):
                         sl.eng.reset()
                         sl.eng.process_device(sl.rd, 0, sl.dev_out)
@@ -398,10 +398,10 @@ def main():
                 lens = hb.lseq.astype(np.int64)
                 n_cig = int(hb.cig_off[-1])
                 ab = int(hb.n * (16 + 8) + ((lens + 1) // 2).sum() + lens.sum() + 4 * n_cig + 4 * n_out_ + 6 * G * 4 + 2 * G * 4)
-                k_alone = float(np.mean(ms[1:]))
+                k_alone = float(np.mean(ms[-4:]))        # (the first ten launches of a fresh multi-GB batch run up to 15 % slower: see launch_ms)
                 sl.eng.close()
                 return {"reads": int(hb.n), "mean_read_len": round(float(lens.mean()), 1), "kernel_ms_alone": round(k_alone, 4),
-                        "ms_per_million_reads": round(k_alone / (hb.n / 1e6), 4), "algorithmic_bytes_per_launch": ab,
+                        "launch_ms": [round(x, 4) for x in ms], "ms_per_million_reads": round(k_alone / (hb.n / 1e6), 4), "algorithmic_bytes_per_launch": ab,
                         "achieved_GBs": round(ab / k_alone / 1e6, 1), "frac_alone": round(ab / k_alone / 1e6 / HBM_PEAK_GBS, 5),
                         "checked": "count table, read statuses, trimmed positions and event count equal oracle/amplipy_oracle.c on the same %d reads (sharded over %d threads)" % (hb.n, cores)}
 
