@@ -1061,7 +1061,9 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // reads of up to 152 bases; the second (amp_fast5.hpp) consumes reads from LDS and takes them up to 304 bases (200 and
     // 250 bp runs: 1.5 x and 1.3 x the first generation, which hands such reads to the general pass)
     const Fast5Cfg f5 = fast5_cfg(n, rd->n_bases_padded, c->window);
-    const int kv0 = c->kernel_variant == 0 ? (f5.waves == 8 ? 4 : 5) : c->kernel_variant;
+    // (a window of 8 makes the first-generation kernel spill 39 registers: 0.354 ms on the bench batch against 0.296 for the second;
+    //  windows 5-7 are its own, 0.274 / 0.294 against 0.30)
+    const int kv0 = c->kernel_variant == 0 ? ((f5.waves == 8 && c->window != 8) ? 4 : 5) : c->kernel_variant;
     const int kv = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
     const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);

@@ -245,7 +245,7 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * events of a batch plus 64 slots per wave of the fast kernel (8 per CU) and of the many-op kernel (24 per CU): waves
  * reserve list slots 64 at a time and leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 0 (default) = chosen per batch between 4 and 5 by its mean padded read length.  4 = the fast kernel (closed-form trim +
+/* 0 (default) = chosen per batch between 4 and 5 by its mean padded read length (up to 152: 4) and the window (8: 5).  4 = the fast kernel (closed-form trim +
  * pileup of reads with one match op or one insertion / deletion of up to 152 bases, every byte loaded once) followed by the
  * general pass over the reads it hands over; 5 = its second generation (reads consumed from LDS staging buffers,
  * branch-free closed forms, reads of up to 304 bases); 2 = the fused tile kernel over every read; 1 = one-lane-per-read

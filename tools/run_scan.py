@@ -9,6 +9,7 @@ ap.add_argument("--depth", type=int, default=10000); ap.add_argument("--iters", 
 ap.add_argument("--variant", type=int, default=4); ap.add_argument("--check", action="store_true")
 ap.add_argument("--indel-frac", type=float, default=0.10)
 ap.add_argument("--read-len", type=int, default=150)
+ap.add_argument("--window", type=int, default=4); ap.add_argument("--min-quality", type=int, default=20)
 ap.add_argument("--same-rows", action="store_true", help="every read points at the bytes of read 0 (timing experiment: no HBM traffic for bases / qualities; results are wrong on purpose)")
 a = ap.parse_args()
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme(); G = g.size
@@ -18,7 +19,7 @@ if a.same_rows:
     b.seq_off8.zero_()
 mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
 e = lib.Engine(G); e.set_kernel_variant(a.variant); e.set_timing(bool(os.environ.get("AMP_SPLIT")))
-e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True); e.reserve_events(max(1 << 20, n // 4))
+e.set_primers(mn, mx, mpl); e.set_params(a.min_quality, a.window, True, True); e.reserve_events(max(1 << 20, n // 4))
 out = {k: torch.zeros(sz, dtype=dt, device="cuda:0") for k, sz, dt in
        (("new_pos", n, torch.int32), ("new_ncig", n, torch.int32), ("new_cig", b.n_cig + 3 * n, torch.int32),
         ("ref_len", n, torch.int32), ("trim_flags", n, torch.uint8), ("status", n, torch.uint8))}
@@ -27,7 +28,7 @@ rd = b.struct()
 ms = []
 for it in range(a.iters):
     e.reset(); e.process_device(rd, 0, dev_out); e.sync(); ms.append(e.last_kernel_ms())
-print("variant %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.depth, n), ["%.3f/%.3f" % m for m in ms])
+print("variant %d window %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.window, a.depth, n), ["%.3f/%.3f" % m for m in ms])
 if not os.environ.get("AMP_STAMPS"): print("general-pass reads of the last launch:", int(e.debug_counters()[7]))
 if os.environ.get("AMP_STAMPS") not in (None, "", "0") and not os.environ.get("AMPLIHIP_PHASES"):
     dc = e.debug_counters()
@@ -76,7 +77,7 @@ if os.environ.get("AMPLIHIP_PHASES"):
 if a.check:
     from oracle import oracle
     hb = b.to_host()
-    ref = oracle.process(hb, G, mn, mx, mpl, 20, 4)
+    ref = oracle.process(hb, G, mn, mx, mpl, a.min_quality, a.window)
     assert np.array_equal(e.counts(), ref.counts), "counts differ"
     assert np.array_equal(out["new_pos"].cpu().numpy(), ref.trim.new_pos)
     assert np.array_equal(out["new_ncig"].cpu().numpy().view(np.uint32), ref.trim.new_ncig)
