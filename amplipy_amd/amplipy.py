@@ -234,10 +234,15 @@ class VcfWriter:
         w("##INFO=<ID=ALT_FREQ,Number=1,Type=String,Description=\"Frequency of alternate base\">\n")
         w("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n")
 
+    def line(self, r):
+        return "%s\t%d\t.\t%s\t%s\t.\tPASS\tDP=%d;REF_DP=%d;ALT_DP=%s;REF_FREQ=%g;ALT_FREQ=%s\tGT\t%s\n" % (
+            self.ref_id, r.pos + 1, r.ref, ",".join(r.alts), r.DP, r.REF_DP, r.ALT_DP, r.REF_FREQ, r.ALT_FREQ, "/".join(map(str, r.GT)))
+
     def write(self, r):
-        info = "DP=%d;REF_DP=%d;ALT_DP=%s;REF_FREQ=%s;ALT_FREQ=%s" % (r.DP, r.REF_DP, r.ALT_DP, "%g" % r.REF_FREQ, r.ALT_FREQ)
-        self.f.write("%s\t%d\t.\t%s\t%s\t.\tPASS\t%s\tGT\t%s\n" % (self.ref_id, r.pos + 1, r.ref, ",".join(r.alts), info,
-                                                                    "/".join(str(g) for g in r.GT)))
+        self.f.write(self.line(r))
+
+    def write_all(self, records):
+        self.f.write("".join([self.line(r) for r in records]))
 
     def close(self):
         if self.f is not sys.stdout:
@@ -502,8 +507,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         if rank != 0:
             run_variants = run_consensus = False       # rank 0 writes the outputs
         if run_variants:
-            for r in res.records:
-                vcf.write(r)
+            vcf.f.write(res.vcf_text(vcf.ref_id))        # (= vcf.write(r) for r in res.records)
             vcf.close()
         if run_consensus:
             f = gzip.open(consensus_fn, "wt") if consensus_fn.lower().endswith(".gz") else open(consensus_fn, "w")

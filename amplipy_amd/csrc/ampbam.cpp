@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -116,19 +117,73 @@ const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06,
 
 struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 
-// byte buffer that is NOT zero-filled on allocation (the inflated image is tens of MB to GB)
+// Big buffers are kept for the next taker instead of being returned to the system.  Releasing one is a munmap, and when the
+// HIP runtime has copied from it (the packed batch goes to the GPU from these very pages) the GPU driver must first tear
+// down its own mapping of them: measured on the GPU box, the HIP call that followed the close of a 1.5 M-read file waited
+// 30-65 ms for that, a third of a `variants` run -- whichever call it was (hipHostMalloc, a kernel launch, hipFree; a
+// 100 ms sleep in between made it vanish, and so did not closing the file).  A piece's buffers also serve the next piece
+// already faulted in.  AMPBAM_POOL_MB bounds what is held (default 4096).
+struct BytePool {
+    std::mutex mu;
+    std::vector<std::pair<uint8_t *, size_t>> idle;
+    size_t held = 0, limit;
+    BytePool() { const char *e = std::getenv("AMPBAM_POOL_MB"); limit = (size_t)(e && e[0] ? std::strtoull(e, nullptr, 10) : 4096ull) << 20; }
+    ~BytePool() { for (auto &b : idle) std::free(b.first); }
+    uint8_t *take(size_t want, size_t &cap) {
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (int i = 0; i < (int)idle.size(); ++i)
+            if (idle[(size_t)i].second >= want && (best < 0 || idle[(size_t)i].second < idle[(size_t)best].second)) best = i;
+        if (best < 0) return nullptr;
+        uint8_t *p = idle[(size_t)best].first; cap = idle[(size_t)best].second;
+        held -= cap;
+        idle.erase(idle.begin() + best);
+        return p;
+    }
+    void give(uint8_t *p, size_t cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (held + cap <= limit) { idle.emplace_back(p, cap); held += cap; return; }
+        }
+        std::free(p);
+    }
+};
+BytePool &byte_pool() { static BytePool P; return P; }
+
+// byte buffer that is NOT zero-filled on allocation (the inflated image is tens of MB to GB).  Buffers of 4 MB and more are
+// 2 MB-aligned and marked MADV_HUGEPAGE: sixteen threads filling a fresh 400 MB image take 100,000 page faults of 4 KB under
+// one mmap lock; with 2 MB pages they are 500 times fewer.  They come from and go back to the pool above.
 struct Bytes {
+    static constexpr size_t HUGE = (size_t)2 << 20;
     uint8_t *p = nullptr;
     size_t n = 0, cap = 0;
     Bytes() = default;
     Bytes(const Bytes &) = delete;
     Bytes &operator=(const Bytes &) = delete;
-    ~Bytes() { std::free(p); }
+    ~Bytes() { drop(); }
+    void drop() {
+        if (p && cap >= 2 * HUGE) byte_pool().give(p, cap); else std::free(p);
+        p = nullptr; n = cap = 0;
+    }
     bool resize(size_t m) {
         if (m > cap) {
-            uint8_t *q = (uint8_t *)std::realloc(p, m);
-            if (!q) return false;
-            p = q; cap = m;
+            if (m >= 2 * HUGE) {
+                size_t want = (m + m / 8 + HUGE - 1) & ~(HUGE - 1);
+                uint8_t *q = byte_pool().take(m, want);
+                if (!q) {
+                    q = (uint8_t *)std::aligned_alloc(HUGE, want);
+                    if (!q) return false;
+                    if (std::getenv("AMPBAM_HUGEPAGES")) (void)madvise(q, want, MADV_HUGEPAGE);
+                }
+                if (n) memcpy(q, p, n);
+                const size_t keep = n;
+                drop();
+                p = q; cap = want; n = keep;
+            } else {
+                uint8_t *q = (uint8_t *)std::realloc(p, m);
+                if (!q) return false;
+                p = q; cap = m;
+            }
         }
         n = m;
         return true;

@@ -77,7 +77,8 @@ struct amp_ctx {
     DBuf scratch;                 // CIGAR scratch for reads whose ops do not fit the LDS slots
     DBuf call_buf;
     DBuf agg_buf;                  // amp_aggregate_ins_events: run records + the sort's scratch
-    void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results
+    void *h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for call results (amp_call_compact_begin: written by the kernel itself)
+    std::vector<uint8_t> h_img; bool img_pinned = false;   // ... and the pageable image of a view that was not begun (one copy)
     bool call_pending = false;     // amp_call_compact_begin has enqueued the calling kernels; amp_call_compact_view picks them up
     amp_call_params call_pending_params{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr;
@@ -894,6 +895,18 @@ int amp_find_overlapping_primers(int32_t ref_len, int32_t n, const int32_t *star
     return AMP_OK;
 }
 
+// Layout of the compact calling image (device and pinned host copy alike)
+struct CallImage {
+    unsigned nblk; size_t off_blk, off_img, img_cons, img_vars, img_rel, img_size;
+    explicit CallImage(int32_t G) {
+        nblk = (unsigned)((G + 255) / 256);
+        off_blk = (size_t)G * sizeof(amp_pos_call);
+        off_img = (off_blk + (size_t)nblk * sizeof(uint2) + 63) & ~(size_t)63;
+        img_cons = 64; img_vars = img_cons + (((size_t)G + 63) & ~(size_t)63);
+        img_rel = img_vars + (size_t)G * sizeof(amp_var_rec); img_size = img_rel + (size_t)G * 4;
+    }
+};
+
 int amp_ctx_create(amp_ctx **out, int device, int32_t ref_len) {
     if (!out || ref_len <= 0) return AMP_EINVAL;
     *out = nullptr;
@@ -1434,44 +1447,44 @@ int amp_call_positions(amp_ctx *c, const amp_call_params *pr, amp_pos_call *out,
     return AMP_OK;
 }
 
-// Layout of the compact calling image (device and pinned host copy alike)
-struct CallImage {
-    unsigned nblk; size_t off_blk, off_img, img_cons, img_vars, img_rel, img_size;
-    explicit CallImage(int32_t G) {
-        nblk = (unsigned)((G + 255) / 256);
-        off_blk = (size_t)G * sizeof(amp_pos_call);
-        off_img = (off_blk + (size_t)nblk * sizeof(uint2) + 63) & ~(size_t)63;
-        img_cons = 64; img_vars = img_cons + (((size_t)G + 63) & ~(size_t)63);
-        img_rel = img_vars + (size_t)G * sizeof(amp_var_rec); img_size = img_rel + (size_t)G * 4;
-    }
-};
-
 // Enqueues the calling kernels on the ctx stream; does not wait.  (The caller has read the image of the ctx's previous call:
 // the views are valid until the next call_* on the ctx.)
-static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr) {
+static int call_compact_enqueue(amp_ctx *c, const amp_call_params *pr, bool pinned) {
     const int32_t G = c->ref_len;
-    // device buffer: [per-position calls][block counts]; pinned host buffer: the output image [totals 64 B][consensus][records]
-    // [relevant positions]
+    // device buffer: [per-position calls][block counts]( + the image when it is copied); host: the output image [totals 64 B]
+    // [consensus][records][relevant positions]
     const CallImage L(G);
-    HIPCHK(c, c->call_buf.ensure(L.off_img + 64));
+    HIPCHK(c, c->call_buf.ensure(L.off_img + (pinned ? 64 : L.img_size)));
     uint8_t *base = c->call_buf.as<uint8_t>();
     amp_pos_call *d_pc = (amp_pos_call *)base;
-    if (c->h_pin_cap < L.img_size) {
-        if (c->h_pin) (void)hipHostFree(c->h_pin);
-        c->h_pin = nullptr; c->h_pin_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_pin, L.img_size, hipHostMallocDefault));
-        c->h_pin_cap = L.img_size;
+    uint8_t *hz;
+    if (pinned) {
+        // Pipelined callers (amp_call_compact_begin): the result image is written by the compaction kernel straight into a
+        // pinned host buffer (plain stores over the host link; half a megabyte): no copy to place.  A copy on a stream of its
+        // own was only served once the kernels queued behind the calls had drained (0.61 ms per step with three steps in flight
+        // instead of 0.31), a copy in the work stream cost a launch gap more (0.308 -> 0.294 ms per bench step with this).
+        if (c->h_pin_cap < L.img_size) {
+            if (c->h_pin) (void)hipHostFree(c->h_pin);
+            c->h_pin = nullptr; c->h_pin_cap = 0;
+            HIPCHK(c, hipHostMalloc(&c->h_pin, L.img_size, hipHostMallocDefault));
+            c->h_pin_cap = L.img_size;
+        }
+        hz = (uint8_t *)c->h_pin;
+    } else {
+        // One-shot callers (a command line: one view per run): no page-locked memory.  In a process that has just mapped and
+        // released hundreds of MB of host memory (a BAM inflated piece by piece) hipHostMalloc / hipHostFree of this 1.5 MB
+        // image took 25-70 ms each (rocprofv3 --hip-trace), a third of a `variants` run over 1.5 M reads; a device image and
+        // one 1.5 MB copy take 0.3 ms.
+        hz = base + L.off_img;
+        if (c->h_img.size() < L.img_size) c->h_img.resize(L.img_size);
     }
-    // The result image is written by the compaction kernel straight into the pinned host buffer (plain stores over the
-    // host link; half a megabyte): no copy to place.  A copy on a stream of its own was only served once the kernels
-    // queued behind the calls had drained (0.61 ms per step with three steps in flight instead of 0.31), a copy in the
-    // work stream cost a launch gap more (0.308 -> 0.294 ms per bench step with this).
-    uint8_t *hz = (uint8_t *)c->h_pin;
     k_call<<<L.nblk, 256, 0, c->stream>>>(c->d_counts, c->d_ins_at, c->d_ref, G, *pr, d_pc, nullptr, (uint2 *)(base + L.off_blk));
     HIPCHK(c, hipGetLastError());
     k_call_compact<<<L.nblk, 256, 0, c->stream>>>(d_pc, c->d_counts, G, (const uint2 *)(base + L.off_blk), (int8_t *)(hz + L.img_cons),
                                                   (amp_var_rec *)(hz + L.img_vars), (int32_t *)(hz + L.img_rel), (unsigned long long *)hz);
     HIPCHK(c, hipGetLastError());
+    if (!pinned) HIPCHK(c, hipMemcpyAsync(c->h_img.data(), hz, L.img_size, hipMemcpyDeviceToHost, c->stream));
+    c->img_pinned = pinned;
     HIPCHK(c, hipEventRecord(c->ev_call, c->stream));     // "the image has arrived"
     return AMP_OK;
 }
@@ -1480,7 +1493,7 @@ int amp_call_compact_begin(amp_ctx *c, const amp_call_params *pr) {
     if (!c || !pr) return AMP_EINVAL;
     if (pr->run_variants && !c->have_ref) return AMP_ESTATE;
     Guard g(c);
-    const int rc = call_compact_enqueue(c, pr);
+    const int rc = call_compact_enqueue(c, pr, true);
     if (rc != AMP_OK) return rc;
     c->call_pending = true; c->call_pending_params = *pr;     // (the view waits for the copy's event, not for what is enqueued behind it)
     return AMP_OK;
@@ -1495,8 +1508,8 @@ int amp_call_compact_view(amp_ctx *c, const amp_call_params *pr, amp_call_view *
     // work enqueued by amp_call_compact_begin with the same parameters is picked up here; anything else starts now
     const bool begun = c->call_pending && memcmp(&c->call_pending_params, pr, sizeof(*pr)) == 0;
     c->call_pending = false;
-    if (!begun) { const int rc = call_compact_enqueue(c, pr); if (rc != AMP_OK) return rc; }
-    uint8_t *hp = (uint8_t *)c->h_pin;
+    if (!begun) { const int rc = call_compact_enqueue(c, pr, false); if (rc != AMP_OK) return rc; }
+    uint8_t *hp = c->img_pinned ? (uint8_t *)c->h_pin : c->h_img.data();
     const unsigned long long *h_nn = (const unsigned long long *)hp;
     const int8_t *h_cons = (const int8_t *)(hp + L.img_cons);
     amp_var_rec *h_vars = (amp_var_rec *)(hp + L.img_vars);

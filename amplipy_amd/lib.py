@@ -254,7 +254,7 @@ class Engine:
 
     def call_compact(self, params):
         """amp_call_compact_view -> (consensus int8[G], VAR_REC_DTYPE[V], relevant int32[R]).  The arrays
-        are views of page-locked memory owned by the engine, valid until the next call_* on it."""
+        are views of host memory owned by the engine, valid until the next call_* on it."""
         G = self.ref_len
         if not hasattr(self, "_cv"):
             self._cv = [abi.AmpCallView(), None, None]

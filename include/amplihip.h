@@ -312,8 +312,9 @@ int amp_call_positions(amp_ctx *ctx, const amp_call_params *params, amp_pos_call
 int amp_call_compact(amp_ctx *ctx, const amp_call_params *params, int8_t *consensus /* [ref_len] */,
                      amp_var_rec *vars, int64_t vars_cap, int64_t *n_vars,
                      int32_t *relevant, int64_t relevant_cap, int64_t *n_relevant);
-/* amp_call_compact without the last copy: the arrays stay in page-locked memory owned by ctx and
- * are valid until the next amp_call_* on the same ctx (or amp_ctx_destroy). */
+/* amp_call_compact without the last copy: the arrays stay in host memory owned by ctx (page-locked and written by the
+ * kernel itself when the call was begun with amp_call_compact_begin, else an ordinary buffer filled by one copy) and are
+ * valid until the next amp_call_* on the same ctx (or amp_ctx_destroy). */
 typedef struct amp_call_view {
     const int8_t *consensus;       /* [ref_len] */
     const amp_var_rec *vars;       /* [n_vars] */

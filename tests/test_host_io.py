@@ -123,3 +123,29 @@ def test_event_store_with_run_counts_and_tallies():
     t = calling.tallies_from_runs(st.counted_pairs({5}), {5})
     assert dict(t[5]) == {"AT": 7, "ATT": 1} and 9 not in t
     assert calling.tallies_from_runs(st.counted_pairs(), {9})[9] == {"AC": 2}
+
+
+def test_vcf_text_equals_the_record_path():
+    """CallResult.vcf_text (the VCF body straight from the columns, what run_amplipy writes) is the text VcfWriter.line gives
+    for every VariantRecord of ``records`` -- positions finished from insertion alleles (``extra``: a replaced record, a
+    dropped one) and reference counts of zero included."""
+    import numpy as np
+    from amplipy_amd import calling
+    from amplipy_amd.amplipy import VcfWriter
+    V, G = 3000, 29903
+    rng = np.random.default_rng(1)
+    pos = np.sort(rng.choice(G, V, replace=False)).astype(np.int32)
+    extra = {int(pos[5]): None,
+             int(pos[9]): calling.VariantRecord(int(pos[9]), "A", ["ACG", "T"], 100, 3, [50, 47], 0.03, [0.5, 0.47], (0, 1, 2)),
+             17: calling.VariantRecord(17, "C", ["CTT"], 40, 0, [40], 0, [1.0], (1,))}
+    res = calling.CallResult("ACGT" * 8000, np.zeros(G, np.int8), {}, pos, rng.integers(100, 10000, V).astype(np.uint32),
+                             rng.integers(0, 100, V).astype(np.uint32), rng.integers(0, 2, V).astype(bool),
+                             rng.integers(1, 4, V).astype(np.int8), rng.integers(0, 6, (V, 6)).astype(np.int8),
+                             rng.integers(1, 50, (V, 6)).astype(np.uint32), extra, None, 0)
+    res.var_ref_count[:50] = 0
+
+    class W(VcfWriter):
+        def __init__(self):
+            self.ref_id = "REF"
+    w = W()
+    assert res.vcf_text("REF") == "".join(w.line(r) for r in res.records)
