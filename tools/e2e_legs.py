@@ -88,7 +88,7 @@ def measure(batch, genome, primers, ref_seq, dev, n_host=1000000, n_bam=150000):
         eng.close(); src.close()
         out["bam_stages_serial_ms"] = {k: round(v, 1) for k, v in stages.items()}
         out["bam_stages_note"] = ("each stage alone on the whole %d-read file with this host's threads; the commands walk the file in pieces of "
-                                  "16 MB (compressed) and run inflate of piece k+1, decode + GPU of piece k and re-encode + deflate of piece k-1 "
+                                  "4 MB (compressed) and run inflate of piece k+1, decode + GPU of piece k and re-encode + deflate of piece k-1 "
                                   "side by side, so a command costs about its longest stage plus start-up" % nb)
     except Exception as ex:
         out["bam_stages_error"] = "%s: %s" % (type(ex).__name__, ex)
