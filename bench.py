@@ -66,12 +66,12 @@ def main():
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4: one job of --depth partitioned over the ranks (strong scaling)")
     ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = chosen per batch by the library)")
-    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: four steps in flight over four streams)")
-    ap.add_argument("--in-flight", type=int, default=4, help="steps in flight (each has its own engine, table and outputs)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (default: eight steps in flight over eight streams)")
+    ap.add_argument("--in-flight", type=int, default=8, help="steps in flight (each has its own engine, table and outputs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs behind the timed region (config 3: 100k x depth; config 5: 8.0 M mixed reads)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps in flight are dealt over (1: the GPU runs step after step; 2+: the next step's reads start on the CUs the last blocks of this step's reads have left)")
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams the steps in flight are dealt over (1: the GPU runs step after step; 2+: the next step's reads start on the CUs the last blocks of this step's reads have left)")
     ap.add_argument("--no-comm-overlap", action="store_true", help="multi-rank runs: all-reduce on the work stream, in front of the step's calls (default: on its own stream, under the next step's reads)")
     args = ap.parse_args()
 
@@ -121,7 +121,7 @@ def main():
     # one block per CU for its whole duration, so on ONE stream the chip idles through every pass's last tile and through the
     # small calling kernels behind it (0.264 ms per step for a 0.234 ms pass); with the next step on another stream its blocks
     # take the CUs as they come free and the small kernels (reset 8, calls 40 / 32 VGPRs, no LDS to speak of) run beside them:
-    # 0.2405 ms with four steps over four streams.  Two steps in flight are not enough for this: the calls of step k then sit
+    # 0.2405 ms with four steps over four streams, 0.233 with eight over eight (the default).  Two steps in flight are not enough for this: the calls of step k then sit
     # behind the blocks of reads(k+1) while the host waits for them with nothing else queued.
     work_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     work_stream = work_streams[0]
