@@ -58,7 +58,10 @@ constexpr int F_MAXLEN = 152;         // longest read the fast path takes: F_NP 
 constexpr int F_PW = 256;             // reference positions covered by a wave's packed window
 constexpr int F_REP = 8;              // replicas of the packed window
 constexpr int F_REPW = F_PW + 1;      // words per replica: one word of skew, so that replica r is shifted by r banks
-constexpr int F_BW = 512;             // reference positions covered by the block's 32-bit window
+#ifndef AMP_F_BW
+#define AMP_F_BW 512
+#endif
+constexpr int F_BW = AMP_F_BW;        // reference positions covered by the block's 32-bit window
 constexpr int F_NPL = 4;              // its base planes: A C G T (a counted N goes straight to the table)
 constexpr int F_BPL = 6;              // ... followed by '-' (deletions) and the insertion-event tally
 constexpr int F_MAXINS = 8;           // longest insertion / deletion of a read the fast path takes

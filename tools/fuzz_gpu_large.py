@@ -14,7 +14,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
 pr = [(s, e) for s, e, _ in primers]
-runners = {v: GpuRunner(variant=v) for v in (2, 3, 4)}
+runners = {v: GpuRunner(variant=v) for v in (2, 3, 4, 5)}
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     off = int(rng.integers(0, 4)); mq = int(rng.choice([13, 20, 30])); w = int(rng.choice([3, 4, 5]))
