@@ -439,7 +439,7 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
                        "parallelism": "coordinate-range partition x%d + one RCCL all-reduce of the count table per step" % world,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
-                       "steps_in_flight": depth, "work_streams": len(work_streams), "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
+                       "steps_in_flight": depth, "work_streams": len(work_streams), "untimed_steps_run": max(args.warmup, depth), "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
                        "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant,
                        "strong_check": strong_check},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
