@@ -239,8 +239,15 @@ struct TileEvSink {
     const TileCtx &t;
     uint32_t read;
     lds_u32 *stage, *cursor;
-    __device__ void add(int32_t r, uint32_t col) { tile_add(t, r, col); }
+    __device__ void add(int32_t r, uint32_t col) {
+#ifndef AMP_ABL_NOADD
+        tile_add(t, r, col);
+#endif
+    }
     __device__ void event(int32_t pos, int32_t lo, int32_t hi) {
+#ifdef AMP_ABL_NOEVENT
+        return;
+#endif
         const uint32_t k = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k < T_EVCAP) {
             stage[k * 4] = (uint32_t)pos; stage[k * 4 + 1] = read; stage[k * 4 + 2] = (uint32_t)lo; stage[k * 4 + 3] = (uint32_t)hi;
