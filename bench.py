@@ -60,8 +60,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 0.23 ms: with eight steps in flight a 20-step region is two and a half pipeline depths long and its fill and drain cost 10 %: 0.248 ms per step at 20, 0.226 at 200, 0.223 at 1000)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--depth", type=int, default=10000, help="mean coverage (10000 -> 1,993,533 reads): per GPU, or of the whole job with --strong")
     ap.add_argument("--strong", action="store_true", help="BASELINE config 4: one job of --depth partitioned over the ranks (strong scaling)")
     ap.add_argument("--cpu-passes", type=int, default=0, help="passes of the CPU baseline over the batch (0 = as many as fit ~10 s; -1 = skip the CPU legs)")
