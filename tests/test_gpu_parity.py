@@ -653,6 +653,62 @@ def test_many_op_reads_of_every_shape(runner, seed, mq, w):
         assert_same(oracle.process(b, G, mn, mx, mpl, mq, w, do_count=False), runner.process(b, G, mn, mx, mpl, mq, w, do_count=False), b, check_counts=False)
 
 
+def _awkward_regular_segments(rng, n, ref_len):
+    """Regular CIGARs (H* S* body S* H*) whose body is ANY sequence of M/=/X/I/D/N ops of 2 to 6 entries: insertions and
+    deletions side by side, first or last in the body, zero-length ops in between; reads at reference position 0, near and
+    over the reference's end; a fifth of the qualities below any threshold used."""
+    from amplipy_amd.segment import Segment
+    segs = []
+    while len(segs) < n:
+        ops = []
+        if rng.random() < 0.1:
+            ops.append((5, int(rng.integers(1, 6))))
+        if rng.random() < 0.35:
+            ops.append((4, int(rng.integers(1, 25))))
+        for _ in range(int(rng.integers(2, 7))):
+            op = int(rng.choice([0, 0, 0, 1, 1, 2, 2, 3, 7, 8]))
+            ops.append((op, 0 if rng.random() < 0.06 else int(rng.integers(1, 40 if op in (0, 7, 8) else 10))))
+        if rng.random() < 0.35:
+            ops.append((4, int(rng.integers(1, 25))))
+        if rng.random() < 0.1:
+            ops.append((5, int(rng.integers(1, 6))))
+        q = sum(k for o, k in ops if o in (0, 1, 4, 7, 8)); span = sum(k for o, k in ops if o in (0, 2, 3, 7, 8))
+        if q == 0 or q > 150:
+            continue
+        r = rng.random()
+        pos = 0 if r < 0.15 else (ref_len - span + int(rng.integers(-3, 6)) if r < 0.3 else int(rng.integers(0, ref_len - span - 1)))
+        pos = max(pos, 0)
+        seq = "".join(rng.choice(list("ACGTN"), q, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        qual = rng.choice([37, 25, 11, 2], q, p=[0.6, 0.2, 0.12, 0.08]).astype(np.uint8)
+        segs.append(Segment(flag=int(rng.choice([0, 16, 99, 147])), reference_start=pos, cigar=ops,
+                            template_length=int(rng.integers(-500, 500)), query_sequence=seq, query_qualities=qual.tolist()))
+    return segs
+
+
+@pytest.mark.parametrize("seed,mq,w", [(11, 20, 4), (12, 13, 3), (13, 30, 8)])
+def test_regular_cigars_with_awkward_indels(runner, seed, mq, w):
+    """What the op-by-op indel walk of the tile kernel (count_regular_ops, amp_read.hpp) has to get right on the device: the
+    run logic of A:730-748 on insertions that are followed by a deletion, by another insertion, by the end clip or by nothing,
+    that start the body or sit at reference position 0 (A:735), reads that leave the reference (statuses in pair order).
+    Statuses of all reads, then trims, count table and events of the reads the reference accepts, with and without trimming."""
+    G = 5000
+    rng = np.random.default_rng(seed)
+    primers = sorted((int(s), int(s) + int(rng.integers(18, 31))) for s in rng.integers(0, G - 40, 40))
+    mn, mx, mpl = oracle.find_overlapping_primers(G, primers, int(rng.integers(0, 3)))
+    segs = _awkward_regular_segments(rng, 6000, G)
+    segs.sort(key=lambda s: s.reference_start)
+    b = ReadBatch.from_segments(segs)
+    for do_trim in (True, False):
+        a = oracle.process(b, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        assert_same(a, runner.process(b, G, mn, mx, mpl, mq, w, do_trim=do_trim), b, check_counts=False)
+        ok = np.nonzero(a.trim.status == 0)[0]
+        assert 0.3 * len(segs) < len(ok) < len(segs)          # both kinds of reads are there
+        good = ReadBatch.from_segments([segs[i] for i in ok])
+        ag = oracle.process(good, G, mn, mx, mpl, mq, w, do_trim=do_trim)
+        assert_same(ag, runner.process(good, G, mn, mx, mpl, mq, w, do_trim=do_trim), good)
+        assert ag.events.size > 500
+
+
 def test_event_text_from_the_staged_batch(scheme):
     """amp_event_strings with reads == NULL (the batch the last amp_process_batch left on the device) gives the allele text
     the host-side gather gives (A:736-738), and fails cleanly before any batch."""
