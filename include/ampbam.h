@@ -13,6 +13,13 @@
  *
  * Every function returns 0 or a negative ampbam_rc; nothing throws across the ABI.  A handle is
  * not thread-safe; the library uses its own worker threads inside a call.
+ *
+ * Memory: buffers of 4 MB and more (inflated images, the packed batch, the writer's blocks) are not returned to the system
+ * when a handle is closed but kept for the next handle of the process, up to AMPBAM_POOL_MB megabytes in all (environment,
+ * default 4096; 0 = keep nothing).  The arrays of a decoded batch are what a GPU runtime copies from, and un-mapping pages it
+ * has mapped for DMA stalls the process's next GPU call by tens of milliseconds; a file walked piece by
+ * piece also finds its next piece's buffers already faulted in.  Other environment switches: AMPBAM_ZLIB=1 (never use
+ * libdeflate), AMPBAM_HUGEPAGES=1 (MADV_HUGEPAGE on those buffers).
  */
 #ifndef AMPBAM_H
 #define AMPBAM_H
