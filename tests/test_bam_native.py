@@ -156,3 +156,52 @@ def test_open_range_parts_tile_the_file(tmp_path):
             for p in parts:
                 p.close()
     whole.close()
+
+
+def test_buffers_handed_from_file_to_file(tmp_path):
+    """The codec keeps its big buffers (inflated image, packed batch, writer blocks: 4 MB and more) for the next file instead
+    of returning them to the system.  A file decoded into buffers that still hold another file's bytes must give exactly
+    what a fresh process gives (the Python codec's rows), padding included, in any order of opening and closing, and a
+    stream written through reused blocks must inflate to the Python writer's."""
+    big = str(tmp_path / "big.bam"); small = str(tmp_path / "small.bam")
+    hb, rb = _make_bam(big, n=26000, seed=5, with_oddities=False)
+    hs, rs = _make_bam(small, n=23000, seed=6, with_oddities=True)
+
+    def expected(recs):
+        return ReadBatch.from_segments([r.to_segment() for r in recs if not (r.flag & 4) and r.cigar is not None])
+
+    def same(got, want):
+        for name in ("pos", "flag", "tlen", "lseq", "cig_off", "cig", "seq_off", "seq", "qual"):
+            assert np.array_equal(getattr(got, name), getattr(want, name)), name
+    wb, ws = expected(rb), expected(rs)
+    assert wb.qual.size >= (4 << 20) and ws.qual.size >= (4 << 20)          # these buffers do go through the pool
+    for path, want in ((big, wb), (small, ws), (big, wb), (small, ws)):
+        f = bam_native.BamFile(path, threads=4)
+        got, _ = f.decode(0, f.n_records)
+        same(got, want)
+        src = got.src_index.copy()                    # (the arrays of a decode are views: the next decode overwrites them)
+        # ... and a second, shorter decode into the same arrays (stale rows behind it must not show)
+        part, _ = f.decode(100, 5000)
+        r0 = int(np.searchsorted(src, 100)); r1 = int(np.searchsorted(src, 5100))
+        assert part.n == r1 - r0 and np.array_equal(part.pos, want.pos[r0:r1]) and np.array_equal(part.lseq, want.lseq[r0:r1])
+        lo, hi = int(want.seq_off[r0]), int(want.seq_off[r1])
+        assert np.array_equal(part.qual[:hi - lo], want.qual[lo:hi]) and np.array_equal(part.seq[:(hi - lo) // 2], want.seq[lo // 2:hi // 2])
+        f.close()
+    # two files open at once, closed in the other order
+    fa = bam_native.BamFile(big, threads=2); fb = bam_native.BamFile(small, threads=2)
+    ga, _ = fa.decode(0, fa.n_records); gb, _ = fb.decode(0, fb.n_records)
+    same(ga, wb); same(gb, ws)
+    # a stream written through reused blocks
+    out_n = str(tmp_path / "n.bam"); out_p = str(tmp_path / "p.bam")
+    n = gb.n
+    keep = np.ones(n, np.uint8); keep[::7] = 0
+    w = bam_native.BamWriter(out_n, hs.text, fb, threads=4)
+    w.write_rows(None, gb.src_index, keep, gb.pos, np.diff(gb.cig_off.astype(np.int64)).astype(np.uint32), gb.cig_off[:-1], gb.cig)
+    w.close()
+    pw = bamio.AlignmentWriter(out_p, "wb", hs)
+    for i, r in enumerate(r for r in rs if not (r.flag & 4) and r.cigar is not None):
+        if keep[i]:
+            pw.write(r)
+    pw.close()
+    assert gzip.decompress(open(out_n, "rb").read()) == gzip.decompress(open(out_p, "rb").read())
+    fa.close(); fb.close()
