@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libampbam.so")
 EXPORTS = [
     "ampbam_version", "ampbam_strerror", "ampbam_open", "ampbam_close", "ampbam_last_error", "ampbam_n_records",
     "ampbam_header_text", "ampbam_n_refs", "ampbam_ref", "ampbam_decode", "ampbam_writer_open", "ampbam_write_rows",
-    "ampbam_writer_close", "ampbam_open_range", "ampbam_part_range",
+    "ampbam_writer_close", "ampbam_open_range", "ampbam_part_range", "ampbam_crc32", "ampbam_inflate_raw",
 ]
 _LIB = None
 
@@ -41,6 +41,9 @@ def load():
         L.ampbam_n_records.restype = C.c_int64
         L.ampbam_n_records.argtypes = [C.c_void_p]
         L.ampbam_n_refs.argtypes = [C.c_void_p]
+        L.ampbam_inflate_raw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.ampbam_crc32.restype = C.c_uint32
+        L.ampbam_crc32.argtypes = [C.c_void_p, C.c_int64]
         L.ampbam_close.restype = None
         L.ampbam_close.argtypes = [C.c_void_p]
         _LIB = L

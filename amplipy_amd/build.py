@@ -51,7 +51,7 @@ def build(force=False, verbose=False, extra_flags=()):
 
 
 BAM_SRC = os.path.join(_HERE, "csrc", "ampbam.cpp")
-BAM_DEPS = [BAM_SRC, os.path.join(_HERE, "..", "include", "ampbam.h")]
+BAM_DEPS = [BAM_SRC, os.path.join(_HERE, "csrc", "amp_inflate.hpp"), os.path.join(_HERE, "..", "include", "ampbam.h")]
 BAM_OUT = os.path.join(_HERE, "libampbam.so")
 
 

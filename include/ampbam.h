@@ -42,6 +42,13 @@ enum ampbam_rc {
 };
 
 int ampbam_version(void);
+/* CRC-32 (gzip polynomial) of a buffer, as the codec computes it for the BGZF blocks it reads and writes (carry-less
+ * multiplication folding on x86 with PCLMULQDQ, zlib's crc32 otherwise: the two must agree, and the tests compare them). */
+uint32_t ampbam_crc32(const void *data, int64_t n_bytes);
+/* The codec's own DEFLATE decoder (amplipy_amd/csrc/amp_inflate.hpp) on one raw stream whose inflated size is known, as it is
+ * run on every BGZF block before zlib gets a block it refuses: 0 when the stream ends with its final block after exactly
+ * n_out bytes, AMPBAM_EFORMAT otherwise (never reads or writes outside the two buffers).  Exposed for the tests. */
+int ampbam_inflate_raw(const void *in, int64_t n_in, void *out, int64_t n_out);
 const char *ampbam_strerror(int rc);
 
 /* ---- reading ---------------------------------------------------------------------------- */

@@ -205,3 +205,118 @@ def test_buffers_handed_from_file_to_file(tmp_path):
     pw.close()
     assert gzip.decompress(open(out_n, "rb").read()) == gzip.decompress(open(out_p, "rb").read())
     fa.close(); fb.close()
+
+
+def test_block_crc_equals_zlibs():
+    """ampbam_crc32 (PCLMULQDQ folding where the CPU has it) against zlib.crc32 on every length from 0 to 300 and on random
+    lengths up to a BGZF block and beyond, unaligned starts included; AMPBAM_ZLIB_CRC=1 selects zlib's for comparison runs."""
+    import zlib
+    L = bam_native.load()
+    rng = np.random.default_rng(9)
+    buf = rng.integers(0, 256, 200000, dtype=np.uint8)
+    base = buf.ctypes.data
+    lens = list(range(0, 301)) + [int(x) for x in rng.integers(301, 70000, 300)] + [65280, 65536, 199999]
+    for n in lens:
+        off = int(rng.integers(0, 17)) if n + 17 < buf.size else 0
+        got = int(L.ampbam_crc32(C.c_void_p(base + off), C.c_int64(n)))
+        assert got == (zlib.crc32(buf[off:off + n].tobytes()) & 0xFFFFFFFF if n else 0), (n, off)
+
+
+def test_own_inflate_against_zlib():
+    """amp_inflate.hpp (the codec's DEFLATE decoder, tried on every BGZF block before zlib) against zlib on raw streams of every
+    compression level and strategy -- stored, fixed-Huffman and dynamic blocks, several blocks per stream, runs (distance 1),
+    long and overlapping matches, incompressible bytes, BAM-like records -- and on damaged input: a truncated stream, flipped
+    bits, random bytes and a wrong expected size must be refused or give bytes that the caller's CRC check then rejects, and
+    never touch memory outside the two buffers (the guard bytes around the output stay intact)."""
+    import zlib
+    L = bam_native.load()
+    rng = np.random.default_rng(17)
+
+    def payloads():
+        yield b""
+        yield b"a"
+        yield b"abc" * 5000
+        yield bytes(60000)
+        yield rng.integers(0, 256, 65280, dtype=np.uint8).tobytes()
+        yield rng.integers(0, 4, 65280, dtype=np.uint8).tobytes()
+        yield bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 40000)) + bytes(rng.choice([37, 37, 37, 25, 11, 2], 25000).astype(np.uint8))
+        rec = bytes(rng.integers(0, 256, 36, dtype=np.uint8)) + b"read_name_%05d\0" + bytes([0x60, 0x09, 0, 0]) + bytes(rng.integers(0, 256, 75, dtype=np.uint8)) + bytes([37] * 150)
+        yield b"".join(rec.replace(b"%05d", b"%05d" % i) for i in range(220))
+        for n in (1, 2, 7, 8, 9, 255, 256, 257, 258, 259, 300, 4095, 32768, 32769, 65535):
+            yield bytes(rng.integers(0, 3, n, dtype=np.uint8))
+
+    def inflate(raw, n_out, pad=64):
+        out = np.full(n_out + 2 * pad, 0xA5, np.uint8)
+        src = np.frombuffer(raw, np.uint8).copy() if raw else np.zeros(1, np.uint8)
+        rc = L.ampbam_inflate_raw(C.c_void_p(src.ctypes.data), C.c_int64(len(raw)), C.c_void_p(out.ctypes.data + pad), C.c_int64(n_out))
+        assert (out[:pad] == 0xA5).all() and (out[pad + n_out:] == 0xA5).all(), "wrote outside the output buffer"
+        return rc, out[pad:pad + n_out].tobytes()
+
+    n_ok = 0
+    for data in payloads():
+        for level in (0, 1, 3, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+                half = len(data) // 2
+                raw = co.compress(data[:half]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(data[half:]) + co.flush()
+                rc, got = inflate(raw, len(data))
+                assert rc == 0 and got == data, (len(data), level, strategy)
+                n_ok += 1
+                if len(data) > 300 and level == 6 and strategy == zlib.Z_DEFAULT_STRATEGY:
+                    assert inflate(raw, len(data) - 1)[0] != 0 and inflate(raw, len(data) + 1)[0] != 0          # wrong ISIZE
+                    assert inflate(raw[:len(raw) // 2], len(data))[0] != 0                                       # truncated
+                    for _ in range(40):                                                                          # flipped bits
+                        bad = bytearray(raw); k = int(rng.integers(0, len(bad))); bad[k] ^= 1 << int(rng.integers(0, 8))
+                        rc2, got2 = inflate(bytes(bad), len(data))
+                        assert rc2 != 0 or got2 == data or zlib.crc32(got2) != zlib.crc32(data)
+    assert n_ok > 500
+    for _ in range(300):                                                                                         # random bytes
+        raw = rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes()
+        inflate(raw, int(rng.integers(0, 70000)))
+
+
+def test_record_index_ignores_decoy_records(tmp_path):
+    """The record index is built by several threads, each of which has to GUESS where a record starts in its stretch of the
+    inflated stream (64 plausible records in a row) before the stretches are stitched along the true chain.  Here long reads
+    carry, in their quality bytes, runs of 70 perfectly plausible fake records: threads that start on one must be overruled.
+    Every number of threads gives the Python codec's rows."""
+    import struct
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    segs = synth.make_mixed_segments(g, amps, 16000, seed=3)
+    hdr = bamio.Header("@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:SYN_REF\tLN:%d\n" % g.size, [("SYN_REF", int(g.size))])
+    fake = struct.pack("<iiiBBHHHIiii", 34, 0, 5, 2, 60, 4680, 0, 0, 0, -1, -1, 0) + b"A\0"
+    assert len(fake) == 38
+    decoy_q = (fake * 70 + bytes([30]) * 40)
+    decoy_q = bytes([30]) * 3 + decoy_q                      # (a first byte of 0xFF would mean "no qualities")
+    recs = []
+    for i, s in enumerate(segs):
+        recs.append(bamio.Rec("r%d" % i, s.flag, 0, s.reference_start, 60, s.cigartuples, 0, s.reference_start, s.template_length,
+                              s.query_sequence, bytes(s.query_qualities)))
+        if i % 150 == 75:
+            L = len(decoy_q)
+            recs.append(bamio.Rec("decoy%d" % i, 0, 0, 100 + i % 1000, 60, [(0, L)], -1, -1, 0, "ACGT" * (L // 4) + "A" * (L % 4), decoy_q))
+    bam = str(tmp_path / "d.bam")
+    w = bamio.AlignmentWriter(bam, "wb", hdr)
+    for r in recs:
+        w.write(r)
+    w.close()
+    want = ReadBatch.from_segments([r.to_segment() for r in recs])
+    for threads in (1, 2, 5, 8, 16):
+        f = bam_native.BamFile(bam, threads=threads)
+        assert f.n_records == len(recs), threads
+        got, skipped = f.decode(0, f.n_records)
+        assert skipped == 0
+        for name in ("pos", "flag", "lseq", "cig_off", "cig", "seq_off", "seq", "qual"):
+            assert np.array_equal(getattr(got, name), getattr(want, name)), (threads, name)
+        f.close()
+    # ... and as parts of a file
+    first_prev = None
+    total = 0
+    for k in range(5):
+        f = bam_native.BamFile(bam, threads=4, part=k, n_parts=5)
+        a, b = f.part_range()
+        assert first_prev is None or a == first_prev
+        first_prev = b
+        total += f.n_records
+        f.close()
+    assert total == len(recs)
