@@ -19,7 +19,8 @@
  * default 4096; 0 = keep nothing).  The arrays of a decoded batch are what a GPU runtime copies from, and un-mapping pages it
  * has mapped for DMA stalls the process's next GPU call by tens of milliseconds; a file walked piece by
  * piece also finds its next piece's buffers already faulted in.  Other environment switches: AMPBAM_ZLIB=1 (never use
- * libdeflate), AMPBAM_HUGEPAGES=1 (MADV_HUGEPAGE on those buffers).
+ * libdeflate), AMPBAM_ZLIB_INFLATE=1 / AMPBAM_ZLIB_CRC=1 (zlib's inflate / crc32 instead of the codec's own, which are tried first
+ * and checked by the block CRC), AMPBAM_HUGEPAGES=1 (MADV_HUGEPAGE on those buffers).
  */
 #ifndef AMPBAM_H
 #define AMPBAM_H
