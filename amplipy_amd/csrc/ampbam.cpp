@@ -274,6 +274,19 @@ struct Bytes {
     size_t size() const { return n; }
 };
 
+// typed array on a Bytes buffer: not zero-filled, pooled like it
+template <class T>
+struct Arr {
+    Bytes b;
+    size_t n = 0;
+    bool resize(size_t m) { if (!b.resize(m * sizeof(T))) return false; n = m; return true; }
+    T *data() { return (T *)b.data(); }
+    const T *data() const { return (const T *)b.data(); }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return ((T *)b.data())[i]; }
+    const T &operator[](size_t i) const { return ((const T *)b.data())[i]; }
+};
+
 }  // namespace
 
 struct ampbam_file {
@@ -291,12 +304,12 @@ struct ampbam_file {
     Bytes hdr;                              // header bytes of parts that do not start at the file's first block
     const uint8_t *text_ptr = nullptr;
     // decode outputs (reused)
-    std::vector<int32_t> pos, tlen;
-    std::vector<uint16_t> flag;
-    std::vector<uint32_t> lseq, cig;
-    std::vector<uint64_t> cig_off, seq_off;
+    Arr<int32_t> pos, tlen;
+    Arr<uint16_t> flag;
+    Arr<uint32_t> lseq, cig;
+    Arr<uint64_t> cig_off, seq_off;
     Bytes seq, qual;
-    std::vector<int64_t> src_index;
+    Arr<int64_t> src_index;
 };
 
 struct ampbam_writer {
@@ -362,54 +375,69 @@ int ampbam_ref(const ampbam_file *f, int32_t i, const char **name, int32_t *leng
 int ampbam_decode(ampbam_file *f, int64_t first, int64_t count, ampbam_batch *out) {
     if (!f || !out || first < 0 || count < 0 || first + count > ampbam_n_records(f)) return AMPBAM_EINVAL;
     const uint8_t *d = f->data.data();
-    // pass 1 (serial, fixed fields only): which records are rows, and where their variable parts go
-    try {
-        f->src_index.clear(); f->cig_off.assign(1, 0); f->seq_off.assign(1, 0);
-        f->src_index.reserve((size_t)count); f->cig_off.reserve((size_t)count + 1); f->seq_off.reserve((size_t)count + 1);
-        uint64_t co = 0, so = 0;
-        for (int64_t r = first; r < first + count; ++r) {
+    // pass 1 (fixed fields only, from the index): which records are rows, and where their variable parts go.  Per chunk of
+    // 4096 records on the threads, an exclusive scan over the chunks, then every chunk fills its own rows in pass 2 (a serial
+    // loop with three push_backs per record was a third of the decode of 1.5 M records).
+    const int64_t grain = 4096, n_chunks = (count + grain - 1) / grain;
+    struct Plan { uint64_t rows, cig, bases; };
+    std::vector<Plan> plan;
+    try { plan.assign((size_t)n_chunks + 1, Plan{0, 0, 0}); } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
+    parallel_for(f->n_threads, n_chunks, [&](int64_t ch) {
+        Plan p{0, 0, 0};
+        for (int64_t r = first + ch * grain; r < std::min(first + count, first + (ch + 1) * grain); ++r) {
             const uint64_t info = f->rec_info[(size_t)r];
             const uint32_t l_seq = (uint32_t)info, n_cig = (uint32_t)(info >> 32) & 0xFFFFu, flag = (uint32_t)(info >> 48);
             if ((flag & 4u) || n_cig == 0) continue;                                    // AmpliPy.py:902
-            f->src_index.push_back(r);
-            co += n_cig; so += ((uint64_t)l_seq + 7) & ~7ull;
-            f->cig_off.push_back(co); f->seq_off.push_back(so);
+            ++p.rows; p.cig += n_cig; p.bases += ((uint64_t)l_seq + 7) & ~7ull;
         }
-        const size_t n = f->src_index.size();
-        f->pos.resize(n); f->tlen.resize(n); f->flag.resize(n); f->lseq.resize(n);
-        f->cig.resize((size_t)co + 4);
-        if (!f->seq.resize((size_t)(so / 2) + 16) || !f->qual.resize((size_t)so + 16)) return AMPBAM_ENOMEM;
-        std::memset(f->seq.data() + so / 2, 0, 16); std::memset(f->qual.data() + so, 0, 16);
-    } catch (const std::bad_alloc &) { return AMPBAM_ENOMEM; }
+        plan[(size_t)ch] = p;
+    });
+    {
+        Plan run{0, 0, 0};
+        for (int64_t ch = 0; ch <= n_chunks; ++ch) { const Plan p = plan[(size_t)ch]; plan[(size_t)ch] = run; run.rows += p.rows; run.cig += p.cig; run.bases += p.bases; }
+    }
+    const int64_t n = (int64_t)plan[(size_t)n_chunks].rows;
+    const uint64_t co = plan[(size_t)n_chunks].cig, so = plan[(size_t)n_chunks].bases;
+    if (!f->src_index.resize((size_t)n) || !f->cig_off.resize((size_t)n + 1) || !f->seq_off.resize((size_t)n + 1) || !f->pos.resize((size_t)n) ||
+        !f->tlen.resize((size_t)n) || !f->flag.resize((size_t)n) || !f->lseq.resize((size_t)n) || !f->cig.resize((size_t)co + 4) ||
+        !f->seq.resize((size_t)(so / 2) + 16) || !f->qual.resize((size_t)so + 16)) return AMPBAM_ENOMEM;
+    f->cig_off[0] = 0; f->seq_off[0] = 0;
+    std::memset(f->cig.data() + co, 0, 16);
+    std::memset(f->seq.data() + so / 2, 0, 16); std::memset(f->qual.data() + so, 0, 16);
     // pass 2 (parallel): copy
-    const int64_t n = (int64_t)f->src_index.size(), grain = 4096;
-    parallel_for(f->n_threads, (n + grain - 1) / grain, [&](int64_t ch) {
-        for (int64_t i = ch * grain; i < std::min(n, (ch + 1) * grain); ++i) {
-            const uint8_t *c = d + f->rec_off[(size_t)f->src_index[(size_t)i]] + 4;
+    parallel_for(f->n_threads, n_chunks, [&](int64_t ch) {
+        int64_t i = (int64_t)plan[(size_t)ch].rows;
+        uint64_t c_at = plan[(size_t)ch].cig, s_at = plan[(size_t)ch].bases;
+        for (int64_t r = first + ch * grain; r < std::min(first + count, first + (ch + 1) * grain); ++r) {
+            const uint64_t info = f->rec_info[(size_t)r];
+            if (((uint32_t)(info >> 48) & 4u) || ((uint32_t)(info >> 32) & 0xFFFFu) == 0) continue;
+            const uint8_t *c = d + f->rec_off[(size_t)r] + 4;
             const uint32_t l_name = c[8], n_cig = le16(c + 12), l_seq = le32(c + 16);
+            const uint64_t padded = ((uint64_t)l_seq + 7) & ~7ull;                        // bases, multiple of 8
+            f->src_index[(size_t)i] = r;
+            f->cig_off[(size_t)i + 1] = c_at + n_cig; f->seq_off[(size_t)i + 1] = s_at + padded;
             f->pos[(size_t)i] = (int32_t)le32(c + 4);
             f->flag[(size_t)i] = le16(c + 14);
             f->lseq[(size_t)i] = l_seq;
             f->tlen[(size_t)i] = (int32_t)le32(c + 28);
             const uint8_t *v = c + 32 + l_name;
-            std::memcpy(&f->cig[(size_t)f->cig_off[(size_t)i]], v, 4ull * n_cig);       // little-endian host
+            std::memcpy(&f->cig[(size_t)c_at], v, 4ull * n_cig);                          // little-endian host
             v += 4ull * n_cig;
-            const uint64_t so = f->seq_off[(size_t)i];
-            const uint64_t padded = f->seq_off[(size_t)i + 1] - so;                       // bases, multiple of 8
-            uint8_t *sq = f->seq.data() + so / 2, *ql = f->qual.data() + so;
+            uint8_t *sq = f->seq.data() + s_at / 2, *ql = f->qual.data() + s_at;
             std::memcpy(sq, v, (l_seq + 1) / 2);
             if (l_seq & 1) sq[l_seq / 2] &= 0xF0;                                      // spare nibble and padding are zero in the batch
             std::memset(sq + (l_seq + 1) / 2, 0, (size_t)(padded / 2 - (l_seq + 1) / 2));
             v += (l_seq + 1) / 2;
             std::memcpy(ql, v, l_seq);
             std::memset(ql + l_seq, 0, (size_t)(padded - l_seq));
+            ++i; c_at += n_cig; s_at += padded;
         }
     });
     out->n_reads = n;
     out->pos = f->pos.data(); out->flag = f->flag.data(); out->tlen = f->tlen.data(); out->lseq = f->lseq.data();
     out->cig_off = f->cig_off.data(); out->cig = f->cig.data(); out->seq_off = f->seq_off.data();
     out->seq = f->seq.data(); out->qual = f->qual.data(); out->src_index = f->src_index.data();
-    out->n_cig = (int64_t)f->cig_off.back(); out->n_bases = (int64_t)f->seq_off.back();
+    out->n_cig = (int64_t)co; out->n_bases = (int64_t)so;
     out->n_skipped = count - n;
     return AMPBAM_OK;
 }
