@@ -353,6 +353,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
 
     print_log("Processing reads...")
     rank_error = None
+    writer_pending = False      # the writer thread of the native BAM path is still running (joined behind the calls)
     ins_store = EventStore()             # insertion events with their allele text (each batch's bases are at hand only now)
     pending = []
     s_i = None
@@ -407,6 +408,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                     except Exception as e:       # surfaced by the main thread
                         werr.append(e)
             wthread = threading.Thread(target=_writer, daemon=True); wthread.start()
+        loop_done = False
         try:
             for piece in src:
                 for first in range(0, piece.n_records, NATIVE_BATCH_READS):
@@ -439,6 +441,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                     wq.put(("close", piece))        # (the writer copies the unchanged parts of a record from the piece's image)
                 else:
                     piece.close()
+            loop_done = True
         except Exception as e:                      # with several ranks the others must not be left waiting in the collective
             if dist is None:
                 raise
@@ -446,13 +449,20 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         finally:
             if wq is not None:
                 wq.put(None)
-                wthread.join()
-        if werr and rank_error is None:
-            if dist is None:
-                raise werr[0]
-            rank_error = werr[0]
-        if nwriter is not None and rank_error is None:
-            nwriter.close()
+                # One process: the writer thread goes on re-encoding and deflating the last rows under the calls and the VCF
+                # text below (32 ms of Python for 12,000 records) and is joined behind them.  Several ranks need to know
+                # whether it failed before the collective.
+                if dist is not None or not loop_done:
+                    wthread.join()
+                else:
+                    writer_pending = True
+        if not writer_pending:
+            if werr and rank_error is None:
+                if dist is None:
+                    raise werr[0]
+                rank_error = werr[0]
+            if nwriter is not None and rank_error is None:
+                nwriter.close()
         seam = getattr(src, "seam", [None, None])
     else:
         seam = [None, None]
@@ -488,7 +498,8 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                 raise rank_error
             raise RuntimeError(trouble)
 
-    if do_count:
+    try:
+      if do_count:
         cp = calling.call_params(min_depth_consensus if min_depth_consensus is not None else 0,
                                  min_freq_consensus if min_freq_consensus is not None else 0,
                                  min_depth_variants if min_depth_variants is not None else 0,
@@ -514,6 +525,14 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             f = gzip.open(consensus_fn, "wt") if consensus_fn.lower().endswith(".gz") else open(consensus_fn, "w")
             f.write(">sample\n%s\n" % res.consensus_string(unknown_symbol))
             f.close()
+    finally:
+        if writer_pending:
+            wthread.join()
+    if writer_pending:
+        if werr:
+            raise werr[0]
+        if nwriter is not None:
+            nwriter.close()
     eng.close()
     parallel.finish(dist)
     if s_i is None:
