@@ -176,6 +176,7 @@ def main():
         depth += 1        # the calls of a step are queued one step later: one more step in flight keeps the host's record assembly under the GPU's work
     slots = [Slot(lane=k) for k in range(depth)]
     pass_ms, fast_ms = [], []
+    step_trace = [] if os.environ.get("BENCH_STEP_TRACE") else None      # development aid: when every step of the timed region was complete
     last = {}
 
     def begin_calls(sl):
@@ -216,6 +217,8 @@ def main():
             last["slot"] = sl
         t, s = sl.eng.last_kernel_ms()
         pass_ms.append(t); fast_ms.append(s)
+        if step_trace is not None:
+            step_trace.append(time.perf_counter())
 
     def run(n):
         for k in range(n):
@@ -232,11 +235,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if step_trace is not None:
+        del step_trace[:]
     run(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if step_trace is not None and rank == 0:
+        ts = [round((x - t0) * 1e3, 3) for x in step_trace]
+        sys.stderr.write("step completion times [ms from the start of the timed region]: %s\nregion %.3f ms\n" % (ts, elapsed * 1e3))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
