@@ -345,8 +345,9 @@ const char *ampbam_last_error(const ampbam_file *f) { return f ? f->err.c_str() 
 
 void ampbam_close(ampbam_file *f) {
     if (!f) return;
-    // returning hundreds of MB of touched pages to the kernel takes ~0.3 ms per MB: not on the caller's clock
-    if (f->data.cap > ((size_t)64 << 20)) std::thread([f]() { delete f; }).detach();
+    // With the buffer pool (the default) closing only hands the buffers back.  Without it (AMPBAM_POOL_MB=0) returning hundreds
+    // of MB of touched pages to the kernel takes ~0.3 ms per MB, which round 2 kept off the caller's clock with a thread.
+    if (byte_pool().limit == 0 && f->data.cap > ((size_t)64 << 20)) std::thread([f]() { delete f; }).detach();
     else delete f;
 }
 
