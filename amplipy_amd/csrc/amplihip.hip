@@ -86,6 +86,7 @@ struct amp_ctx {
     bool last_split = false;      // the last launch recorded ev1 / ev2
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
+    int cu_share = 1;              // the fast kernels of this ctx are sized for n_cu / cu_share CUs (amp_set_cu_share)
     int kernel_variant = 0;       // 0 = by the batch (4 for reads of up to 152 padded bases on average, else 5), 5 = fast kernel (second generation) + general pass, 4 = its first generation, 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
                                   // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
@@ -1017,6 +1018,12 @@ int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kern
     return AMP_OK;
 }
 
+int amp_set_cu_share(amp_ctx *c, int divisor) {
+    if (!c || divisor < 1 || divisor > 16) return AMP_EINVAL;
+    c->cu_share = divisor;
+    return AMP_OK;
+}
+
 int amp_set_timing(amp_ctx *c, int split) {
     if (!c) return AMP_EINVAL;
     c->split_timing = split != 0;
@@ -1057,7 +1064,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         for (int s = 0; s < EV_SHARDS; ++s) mx = std::max(mx, h[16 + s]);
         // any shard may receive every new event; the fast kernel reserves list slots a granule at a time (a refill
         // leaves fewer slots unused than the tile that caused it needs, plus one open granule per wave at the end)
-        const FastGrid fgb = fast_grid(n, c->n_cu);
+        const FastGrid fgb = fast_grid(n, std::max(1, c->n_cu / c->cu_share));
         // (k_long's waves own granules too: amp_wave.hpp)
         const int64_t need = (int64_t)(mx + 2 * h[1]) + fgb.grid * F_WAVES * (int64_t)F_EVGRAN + 2 * (int64_t)c->n_cu * L_WAVES * L_EVCAP;
         if (need > c->ev_cap) HIPCHK(c, grow_events(c, std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2)));
@@ -1080,7 +1087,8 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const int kv = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
     const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
-    const FastGrid fg = kv == 5 ? fast5_grid(n, c->n_cu, f5) : fast_grid(n, c->n_cu);
+    const int fast_cus = std::max(1, c->n_cu / c->cu_share);
+    const FastGrid fg = kv == 5 ? fast5_grid(n, fast_cus, f5) : fast_grid(n, fast_cus);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without

@@ -24,7 +24,7 @@ EXPORTS = [
     "amp_process_batch_device", "amp_sync", "amp_last_kernel_ms", "amp_get_counts", "amp_add_counts",
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
-    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events",
+    "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events", "amp_set_cu_share",
     "amp_aggregate_ins_events",
 ]
 
@@ -115,6 +115,10 @@ class Engine:
 
     def set_kernel_variant(self, v):
         self._chk(self.L.amp_set_kernel_variant(self.h, C.c_int(v)), "amp_set_kernel_variant")
+
+    def set_cu_share(self, divisor):
+        """The fast kernel's grid for 1 / divisor of the CUs: for several engines in flight on different streams."""
+        self._chk(self.L.amp_set_cu_share(self.h, C.c_int(divisor)), "amp_set_cu_share")
 
     def set_stream(self, hip_stream):
         self._chk(self.L.amp_ctx_set_stream(self.h, C.c_void_p(hip_stream)), "amp_ctx_set_stream")

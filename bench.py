@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file legs behind the timed region")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs behind the timed region (config 3: 100k x depth; config 5: 8.0 M mixed reads)")
     ap.add_argument("--streams", type=int, default=8, help="HIP streams the steps in flight are dealt over (1: the GPU runs step after step; 2+: the next step's reads start on the CUs the last blocks of this step's reads have left)")
+    ap.add_argument("--cu-share", type=int, default=0, help="size each step's scan pass for 1 / N of the CUs (0 = 2 when the steps are dealt over several streams, else 1)")
     ap.add_argument("--no-comm-overlap", action="store_true", help="multi-rank runs: all-reduce on the work stream, in front of the step's calls (default: on its own stream, under the next step's reads)")
     args = ap.parse_args()
 
@@ -123,7 +124,11 @@ def main():
     # take the CUs as they come free and the small kernels (reset 8, calls 40 / 32 VGPRs, no LDS to speak of) run beside them:
     # 0.2405 ms with four steps over four streams, 0.233 with eight over eight (the default).  Two steps in flight are not enough for this: the calls of step k then sit
     # behind the blocks of reads(k+1) while the host waits for them with nothing else queued.
-    work_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    work_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, 1 if args.no_pipeline else args.streams))]
+    # ... and every pass is sized for HALF the CUs: two passes side by side finish sooner than one after the other on the whole
+    # chip (a block works twice as long, so its start-up, its flush and the idle end of its last round of tiles weigh half as
+    # much: 0.224 -> 0.212 ms per step).  The solo leg behind the timed region runs the pass alone and therefore on all CUs.
+    cu_share = args.cu_share if args.cu_share > 0 else (2 if len(work_streams) > 1 else 1)
     work_stream = work_streams[0]
     # multi-rank runs: the step's one collective goes to a stream of its own.  xGMI moves the 0.8 MB table while the work
     # stream already runs the next step's reads (other slot, other table); the step's calls are queued behind those reads
@@ -137,6 +142,7 @@ def main():
             self.stream = work_streams[lane % len(work_streams)]
             self.eng = eng = lib.Engine(G, device=local_rank)
             eng.set_kernel_variant(args.variant)
+            eng.set_cu_share(cu_share)
             eng.set_stream(self.stream.cuda_stream)
             self.table = torch.zeros(G * 7, dtype=torch.int32, device=dev)   # counts [G][6] + insertion tally [G]
             eng.bind_counts(self.table.data_ptr())
@@ -254,15 +260,18 @@ def main():
     # overlap them with the previous step's small kernels and with the next scan, which stretches their
     # own duration while shortening the step)
     solo_pass, solo_fast = [], []
-    for it in range(8):
-        eng.set_timing(it >= 5)          # the last three also time the first kernel of the pass on its own (which costs an idle gap)
+    eng.set_cu_share(1)                  # alone, the pass has the whole chip
+    for it in range(11):                 # three untimed passes on the new grid, five timed, three with the first kernel timed on its own
+        eng.set_timing(it >= 8)          # (timing the first kernel of the pass on its own costs an idle gap)
         with torch.cuda.stream(last["slot"].stream):
             eng.reset()
             eng.process_device(rd, 0, last["slot"].dev_out)
             eng.sync()
         t, s = eng.last_kernel_ms()
-        (solo_pass if it < 5 else solo_fast).append(t if it < 5 else s)
+        if it >= 3:
+            (solo_pass if it < 8 else solo_fast).append(t if it < 8 else s)
     eng.set_timing(False)
+    eng.set_cu_share(cu_share)
     if dist is not None:     # leave the engine with the reduced table again (the check below and the calls use it)
         with torch.cuda.stream(last["slot"].stream):
             parallel.allreduce_table(dist, table)
@@ -447,7 +456,7 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": L, "ref_len": G, "min_quality": 20, "window": 4,
                        "parallelism": "coordinate-range partition x%d + one RCCL all-reduce of the count table per step" % world,
                        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
-                       "steps_in_flight": depth, "work_streams": len(work_streams), "untimed_steps_run": max(args.warmup, depth), "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
+                       "steps_in_flight": depth, "work_streams": len(work_streams), "cu_share_of_a_pass": "1/%d" % cu_share, "untimed_steps_run": max(args.warmup, depth), "collective_on_own_stream": comm_stream is not None, "kernel_variant": args.variant, "error_reads": n_err,
                        "variants_called": res.n_records, "ins_relevant_positions": res.n_relevant,
                        "strong_check": strong_check},
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
@@ -466,9 +475,10 @@ def main():
                                   if len(work_streams) > 1 else
                                   "kernel_ms / achieved / frac: HIP events around ALL kernels of the scan pass (amp_process_batch_device) "
                                   "inside the timed region, on the one work stream. ")
-                                 + "kernel_ms_alone / frac_alone: the same launches with the GPU to itself (5 passes after the timed "
-                                   "region, HIP events on the engine's stream; profiles/ hold the rocprofv3 kernel trace of this leg); "
-                                   "fast_kernel_ms_alone: the first kernel of the pass alone (k_fast for variant 4)"},
+                                 + ("kernel_ms_alone / frac_alone: the pass with the GPU to itself and its grid sized for all CUs (5 passes after "
+                                    "the timed region, HIP events on the engine's stream; profiles/ hold the rocprofv3 kernel trace of this "
+                                    "leg); inside the region a pass is sized for 1/%d of the CUs (amp_set_cu_share) and passes run side by side; "
+                                    "fast_kernel_ms_alone: the first kernel of the pass alone (k_fast for variant 4)" % cu_share)},
             "cpu_baseline": cpu,
             "e2e": e2e,
             "extra": extra,

@@ -252,6 +252,12 @@ int amp_reserve_events(amp_ctx *ctx, int64_t cap);
  * kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks (all give
  * identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
+/* Size the fast kernel's grid for 1 / divisor of the GPU's CUs (1, the default: one block per CU).  For callers that keep
+ * several batches in flight on different streams (one ctx each): two passes side by side on half the chip each finish
+ * sooner than one after the other on all of it -- a block then works twice as long, so its start-up, its flush and the idle
+ * end of its last round of tiles weigh half as much (bench.py: 0.224 -> 0.212 ms per 2 M-read step with divisor 2, eight
+ * steps in flight).  A pass that runs alone should keep the default.  Results do not depend on it. */
+int amp_set_cu_share(amp_ctx *ctx, int divisor);
 
 /* ---- calling: alleles_from_counts (AmpliPy.py:756-771) + the loop AmpliPy.py:917-952 --------
  * One device pass decides, for every reference position, everything that does not depend on

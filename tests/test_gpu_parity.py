@@ -709,6 +709,28 @@ def test_regular_cigars_with_awkward_indels(runner, seed, mq, w):
         assert ag.events.size > 500
 
 
+def test_cu_share_does_not_change_results(runner, scheme):
+    """amp_set_cu_share sizes the fast kernel's grid for a part of the chip (callers with several batches in flight run their
+    passes side by side): trims, table and events must not depend on it -- plain reads, indel reads handed to the general
+    pass and a batch spread thinly over the reference alike."""
+    if runner.variant not in (4, 5):
+        pytest.skip("only the fast kernels have a grid to size")
+    g, pr, amps, mn, mx, mpl = scheme
+    batches = [synth.make_amplicon_batch(g, amps, 60000, seed=8),
+               ReadBatch.from_segments(sorted(synth.make_mixed_segments(g, amps, 9000, seed=9), key=lambda s: s.reference_start))]
+    eng = runner.engine(g.size)
+    try:
+        for b in batches:
+            a = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+            for share in (1, 2, 3, 16):
+                eng.set_cu_share(share)
+                assert_same(a, runner.process(b, g.size, mn, mx, mpl, 20, 4), b)
+    finally:
+        eng.set_cu_share(1)
+    with pytest.raises(Exception):
+        eng.set_cu_share(0)
+
+
 def test_event_text_from_the_staged_batch(scheme):
     """amp_event_strings with reads == NULL (the batch the last amp_process_batch left on the device) gives the allele text
     the host-side gather gives (A:736-738), and fails cleanly before any batch."""
