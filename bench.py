@@ -298,6 +298,7 @@ def main():
     if args.strong and rank == 0:
         # bit-identity of the stitched table with the whole job on ONE GPU (A:896-915 is an order-free integer sum)
         one = Slot(whole)
+        one.eng.set_cu_share(1)
         with torch.cuda.stream(one.stream):
             one.eng.reset()
             one.eng.process_device(one.rd, 0, one.dev_out)
@@ -387,6 +388,7 @@ def main():
                 """db: DeviceBatch, hb: the same rows on the host -> dict with the scan pass's duration alone and its roofline
                 fraction; asserts count table, trimmed positions and event count against the sharded oracle."""
                 sl = Slot(db)
+                sl.eng.set_cu_share(1)          # one launch alone: the whole chip
                 ms = []
                 for it in range(14):
                     with torch.cuda.stream(sl.stream):
