@@ -21,6 +21,7 @@
 #include "amp_tile.hpp"
 #include "amp_fast.hpp"
 #include "amp_fast5.hpp"
+#include "amp_fast6.hpp"
 #include "amp_wave.hpp"
 #include "amp_ins.hpp"
 
@@ -1013,7 +1014,7 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
 }
 
 int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 / 5 = fast kernel (first / second generation) + general pass
-    if (!c || variant < 0 || variant > 5) return AMP_EINVAL;
+    if (!c || variant < 0 || variant > 6) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -1084,11 +1085,12 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // (a window of 8 makes the first-generation kernel spill 39 registers: 0.354 ms on the bench batch against 0.296 for the second;
     //  windows 5-7 are its own, 0.274 / 0.294 against 0.30)
     const int kv0 = c->kernel_variant == 0 ? ((f5.waves == 8 && c->window != 8) ? 4 : 5) : c->kernel_variant;
-    const int kv = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
-    const int variant = kv == 5 ? 4 : kv;          // (5 differs from 4 in the fast kernel only)
+    const int kv1 = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
+    const int kv = (kv1 == 6 && c->min_quality < 1) ? 4 : kv1;      // (the third generation tells a masked base by its zeroed code: with min_quality 0 the pad bases of a row would count as kept)
+    const int variant = kv >= 5 ? 4 : kv;          // (5 and 6 differ from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
     const int fast_cus = std::max(1, c->n_cu / c->cu_share);
-    const FastGrid fg = kv == 5 ? fast5_grid(n, fast_cus, f5) : fast_grid(n, fast_cus);
+    const FastGrid fg = kv == 6 ? fast6_grid(n, fast_cus) : kv == 5 ? fast5_grid(n, fast_cus, f5) : fast_grid(n, fast_cus);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without
@@ -1100,7 +1102,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // a batch of reads with many CIGAR ops (eight a read on average: Nanopore-like) gets k_long (amp_wave.hpp) for them; the
     // results do not depend on this choice
     const bool long_kernel = variant == 4 && rd->n_cig >= 8 * n;
-    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + 1024 + (long_kernel ? 2 * (size_t)n : 0) : 0;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + 1024 + (long_kernel ? 2 * (size_t)n : 0) + (kv == 6 ? (size_t)fg.grid * (size_t)fg.rpb : 0) : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
@@ -1130,7 +1132,10 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         // fast pass over the simple reads, then the general tile kernel over the list of the others
         const SplitDesc none{nullptr, nullptr, nullptr, nullptr};
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        if ((kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, f5, c->stream)
+        uint32_t *segfirst0 = (uint32_t *)geo + 4;
+        uint32_t *clist = segfirst0 + 1024 + (long_kernel ? 2 * (size_t)n : 0);      // (variant 6) the blocks' class lists
+        if ((kv == 6 ? fast6_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, clist, fg, c->stream)
+             : kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, f5, c->stream)
                      : fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64)) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;
         }
