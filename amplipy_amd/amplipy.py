@@ -153,22 +153,22 @@ class NativeInput:
         self._first = None
         self._ahead = None          # (thread, box) of the piece being opened
 
-    def _open(self, k):
+    def _open(self, k, first_hint=None):
         from . import bam_native
-        return bam_native.BamFile(self.path, part=k, n_parts=self.n_parts)
+        return bam_native.BamFile(self.path, part=k, n_parts=self.n_parts, first_hint=first_hint)
 
     def first_part(self):
         if self._first is None:
             self._first = self._open(self.k_lo)
         return self._first
 
-    def _start(self, k):
+    def _start(self, k, first_hint):
         import threading
         box = {}
 
         def run():
             try:
-                box["file"] = self._open(k)
+                box["file"] = self._open(k, first_hint)
             except Exception as e:           # surfaced by the consumer
                 box["error"] = e
         t = threading.Thread(target=run, daemon=True)
@@ -183,10 +183,13 @@ class NativeInput:
         cur = self.first_part()
         self._first = None
         for k in range(self.k_lo, self.k_hi):
+            # the piece behind this one starts where this one ends: it is told so, and only the rank's FIRST piece (whose
+            # predecessor another rank reads) is found by the codec's chain-of-plausible-records search
+            a, b = cur.part_range()
             if k + 1 < self.k_hi:
-                self._start(k + 1)
+                exact = cur.n_records > 0 or k > self.k_lo or self.k_lo == 0      # (a guessed piece without records does not know where it ends)
+                self._start(k + 1, b if exact else None)
             if cur.n_records:
-                a, b = cur.part_range()
                 if prev_end is not None and a != prev_end:
                     raise bam_native_error("%s: piece %d of %d starts at inflated offset %d, the piece before it ended at %d"
                                            % (self.path, k, self.n_parts, a, prev_end))

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libampbam.so")
 EXPORTS = [
     "ampbam_version", "ampbam_strerror", "ampbam_open", "ampbam_close", "ampbam_last_error", "ampbam_n_records",
     "ampbam_header_text", "ampbam_n_refs", "ampbam_ref", "ampbam_decode", "ampbam_writer_open", "ampbam_write_rows",
-    "ampbam_writer_close", "ampbam_open_range", "ampbam_part_range", "ampbam_crc32", "ampbam_inflate_raw",
+    "ampbam_writer_close", "ampbam_open_range", "ampbam_open_range_at", "ampbam_part_range", "ampbam_crc32", "ampbam_inflate_raw",
 ]
 _LIB = None
 
@@ -65,13 +65,15 @@ def _view(addr, dtype, count):
 class BamFile:
     """A BAM file inflated into host memory; records are addressed by number."""
 
-    def __init__(self, path, threads=0, part=0, n_parts=1):
+    def __init__(self, path, threads=0, part=0, n_parts=1, first_hint=None):
         """part / n_parts: only that share of the file (ampbam_open_range: cut by compressed bytes at BGZF-block starts; records
-        are numbered from the part's first one)."""
+        are numbered from the part's first one).  first_hint: the inflated offset at which the part before this one ended, when
+        the caller knows it (ampbam_open_range_at: the part's first record is then not guessed)."""
         self.L = load()
         h = C.c_void_p()
         self.part, self.n_parts = int(part), int(n_parts)
-        rc = self.L.ampbam_open_range(os.fsencode(path), C.c_int(threads), C.c_int(part), C.c_int(n_parts), C.byref(h))
+        hint = 0xFFFFFFFFFFFFFFFF if first_hint is None else int(first_hint)
+        rc = self.L.ampbam_open_range_at(os.fsencode(path), C.c_int(threads), C.c_int(part), C.c_int(n_parts), C.c_uint64(hint), C.byref(h))
         if rc:
             raise AmpBamError("%s: %s" % (path, self.L.ampbam_strerror(rc).decode()))
         self.h = h

@@ -41,22 +41,52 @@
 
 namespace amp {
 
+// ablation builds (development: parts of the kernel switched off to time the rest; results are wrong on purpose)
+#ifndef AMP_F6_ABL
+#define AMP_F6_ABL 0
+#endif
 constexpr int F6_WAVES = 8;
 constexpr int F6_NP = 10;                  // 16-base pieces of a row
 constexpr int F6_MAXLEN = 16 * F6_NP;      // longest read taken
 constexpr int F6_QB = 1024 * F6_NP;        // bytes of a wave's quality image (10 instructions x 64 lanes x 16 bytes)
 constexpr int F6_SB = 512 * F6_NP;         // ... of its base image (5 instructions)
 constexpr int F6_PW = 224;                 // reference positions covered by a wave's packed window
-constexpr int F6_REP = 4;                  // replicas of it (replica r is skewed by r banks)
-constexpr int F6_REPW = F6_PW + 1;
+constexpr int F6_REP = 4;                  // replicas of it
+constexpr int F6_REPW = F6_PW + 3;         // words per replica: replica r is skewed by 3 r banks (tools/micro/lds_pile.hip: with replica (lane >> 1) & 3
+                                           // an add costs 4.0 - 4.7 LDS cycles on piles whose reads start within 3 .. 64 positions, against 8 for a skew of one bank)
 constexpr int F6_BW = 480;                 // positions of the block's 32-bit window
 constexpr int F6_FLUSH = 7;                // tiles between two folds: a counter gets at most 64 / F6_REP = 16 increments per tile, G has 7 bits
 constexpr uint32_t F6_LUT_LO = 0xFF10081Fu, F6_LUT_HI = 0xFFFFFF18u;      // shift count by code: 0 -> 31, A -> 8, C -> 16, G -> 24; T (8) -> 0 by the sign selector
 
 // LDS-DMA of 16 bytes per lane: global address g + OFF, LDS address m0 + OFF + 16 * lane (issued where the compiler cannot see it)
 template <int OFF>
-__device__ __forceinline__ void dma16_off(const void *g, uint32_t m0v) {
+__device__ __forceinline__ void dma16_off(const void *g, uint32_t m0v_) {
+    const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0v_);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(m0v), "n"(OFF) : "memory", "m0");
+}
+// the ten instructions of a tile's quality rows in one statement: 16 bytes per lane from (rows 32 .. 63 ? go : ge) + 32 j to
+// lds + 1024 (2 j + (rows 32 .. 63)) + 16 lane (m0 + the instruction's offset + 16 lane).  The five instructions of a half of the
+// rows follow each other: a 128-byte line of a row is touched by up to four of them, and the fewer lines a wave keeps alive in
+// the 32 KB vector cache of its CU (eight waves stream through it), the fewer are fetched from L2 twice
+__device__ __forceinline__ void dma_q_rows(const void *ge, const void *go, uint32_t lds_) {
+    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\ts_add_u32 m0, m0, 2016\n\tglobal_load_lds_dwordx4 %0, off offset:32\n\ts_add_u32 m0, m0, 2016\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:64\n\ts_add_u32 m0, m0, 2016\n\tglobal_load_lds_dwordx4 %0, off offset:96\n\ts_add_u32 m0, m0, 2016\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:128\n\ts_sub_u32 m0, m0, 7040\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 2016\n\tglobal_load_lds_dwordx4 %1, off offset:32\n\ts_add_u32 m0, m0, 2016\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:64\n\ts_add_u32 m0, m0, 2016\n\tglobal_load_lds_dwordx4 %1, off offset:96\n\ts_add_u32 m0, m0, 2016\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:128"
+                 : : "v"(ge), "v"(go), "s"(lds) : "memory", "m0");
+}
+// the five instructions of its rows of packed bases: instruction c moves 16 bytes from g + 16 c to lds + 1024 c + 16 lane
+__device__ __forceinline__ void dma_s_rows(const void *g, uint32_t lds_) {
+    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\ts_add_u32 m0, m0, 1008\n\tglobal_load_lds_dwordx4 %0, off offset:16\n\ts_add_u32 m0, m0, 1008\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:32\n\ts_add_u32 m0, m0, 1008\n\tglobal_load_lds_dwordx4 %0, off offset:48\n\ts_add_u32 m0, m0, 1008\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:64"
+                 : : "v"(g), "s"(lds) : "memory", "m0");
 }
 
 // 16 failing-window bits of a piece for windows of 4: bit b <=> bytes b .. b+3 of (q, nx) sum to < thr (nthr = 65536 - thr in every half)
@@ -105,16 +135,21 @@ __device__ __forceinline__ uint2 f6_range_nibbles(int32_t klo, int32_t khi) {
     const uint32_t a = (uint32_t)lin, b = (uint32_t)(lin >> 32);
     return make_uint2(((a & 0x0F0F0F0Fu) << 4) | ((a >> 4) & 0x0F0F0F0Fu), ((b & 0x0F0F0F0Fu) << 4) | ((b >> 4) & 0x0F0F0F0Fu));
 }
-// counter word at wb + 4 * B  +=  1 << (byte J of sh)
-template <int J, int B>
-__device__ __forceinline__ void f6_add(uint32_t wb, uint32_t sh, uint32_t one) {
-    uint32_t t;
-    if (J == 0) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(one), "v"(wb), "n"(4 * B) : "memory");
-    if (J == 1) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(one), "v"(wb), "n"(4 * B) : "memory");
-    if (J == 2) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(one), "v"(wb), "n"(4 * B) : "memory");
-    if (J == 3) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\tds_add_u32 %3, %0 offset:%4" : "=&v"(t) : "v"(sh), "v"(one), "v"(wb), "n"(4 * B) : "memory");
+// the 16 bases of a piece (masked codes m) into the counter words from wb on.  The adds of a piece are ONE asm statement: shift
+// counts se / so hold the even / odd bases of a half (byte j = base 2j resp. 2j + 1), `one' << count goes to word wb + 4 * base
+#define F6_SH(d, sh, j) "v_lshlrev_b32_sdwa " d ", " sh ", %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #j " src1_sel:DWORD\n\t"
+template <int B0>
+__device__ __forceinline__ void f6_add8(uint32_t wb, uint32_t se, uint32_t so, uint32_t one) {
+    uint32_t t0, t1;
+    asm volatile(F6_SH("%0", "%4", 0) F6_SH("%1", "%5", 0)
+                 "ds_add_u32 %2, %0 offset:%6\n\t" F6_SH("%0", "%4", 1) "ds_add_u32 %2, %1 offset:%7\n\t" F6_SH("%1", "%5", 1)
+                 "ds_add_u32 %2, %0 offset:%8\n\t" F6_SH("%0", "%4", 2) "ds_add_u32 %2, %1 offset:%9\n\t" F6_SH("%1", "%5", 2)
+                 "ds_add_u32 %2, %0 offset:%10\n\t" F6_SH("%0", "%4", 3) "ds_add_u32 %2, %1 offset:%11\n\t" F6_SH("%1", "%5", 3)
+                 "ds_add_u32 %2, %0 offset:%12\n\tds_add_u32 %2, %1 offset:%13"
+                 : "=&v"(t0), "=&v"(t1) : "v"(wb), "v"(one), "v"(se), "v"(so),
+                   "n"(4 * B0), "n"(4 * B0 + 4), "n"(4 * B0 + 8), "n"(4 * B0 + 12), "n"(4 * B0 + 16), "n"(4 * B0 + 20), "n"(4 * B0 + 24), "n"(4 * B0 + 28) : "memory");
 }
-// the 16 bases of a piece (masked codes m) into the counter words from wb on
+#undef F6_SH
 __device__ __forceinline__ void f6_count16(const uint2 &m, uint32_t wb, uint32_t one, uint32_t &badacc) {
     const uint32_t se0 = __builtin_amdgcn_perm(F6_LUT_HI, F6_LUT_LO, (m.x >> 4) & 0x0F0F0F0Fu);      // even bases of the first half
     const uint32_t so0 = __builtin_amdgcn_perm(F6_LUT_HI, F6_LUT_LO, m.x & 0x0F0F0F0Fu);
@@ -122,11 +157,37 @@ __device__ __forceinline__ void f6_count16(const uint2 &m, uint32_t wb, uint32_t
     const uint32_t so1 = __builtin_amdgcn_perm(F6_LUT_HI, F6_LUT_LO, m.y & 0x0F0F0F0Fu);
     // codes that are not one of A C G T: bit 7 of the shift count, or code 12 (which the permute turns into a zero like T's)
     badacc |= ((se0 | so0 | se1 | so1) & 0x80808080u) | (((m.x & (m.x >> 1)) | (m.y & (m.y >> 1))) & 0x44444444u);
-    f6_add<0, 0>(wb, se0, one);  f6_add<0, 1>(wb, so0, one);  f6_add<1, 2>(wb, se0, one);  f6_add<1, 3>(wb, so0, one);
-    f6_add<2, 4>(wb, se0, one);  f6_add<2, 5>(wb, so0, one);  f6_add<3, 6>(wb, se0, one);  f6_add<3, 7>(wb, so0, one);
-    f6_add<0, 8>(wb, se1, one);  f6_add<0, 9>(wb, so1, one);  f6_add<1, 10>(wb, se1, one); f6_add<1, 11>(wb, so1, one);
-    f6_add<2, 12>(wb, se1, one); f6_add<2, 13>(wb, so1, one); f6_add<3, 14>(wb, se1, one); f6_add<3, 15>(wb, so1, one);
+    if (AMP_F6_ABL & 1) { asm volatile("" : : "v"(wb), "v"(se0 + so0 + se1 + so1)); return; }
+    f6_add8<0>(wb, se0, so0, one);
+    f6_add8<8>(wb, se1, so1, one);
 }
+
+// minimum over the lanes of the wave (DPP row shifts and row broadcasts, no LDS traffic); the result is uniform
+__device__ __forceinline__ int32_t wave_min_i32(int32_t x) {
+    int32_t t = x, u;
+    const int32_t big = 0x7FFFFFFF;
+    u = __builtin_amdgcn_update_dpp(big, t, 0x111, 0xF, 0xF, false); t = u < t ? u : t;      // row_shr:1
+    u = __builtin_amdgcn_update_dpp(big, t, 0x112, 0xF, 0xF, false); t = u < t ? u : t;      // row_shr:2
+    u = __builtin_amdgcn_update_dpp(big, t, 0x114, 0xF, 0xF, false); t = u < t ? u : t;      // row_shr:4
+    u = __builtin_amdgcn_update_dpp(big, t, 0x118, 0xF, 0xF, false); t = u < t ? u : t;      // row_shr:8
+    u = __builtin_amdgcn_update_dpp(big, t, 0x142, 0xA, 0xF, false); t = u < t ? u : t;      // row_bcast:15 into rows 1 and 3
+    u = __builtin_amdgcn_update_dpp(big, t, 0x143, 0xC, 0xF, false); t = u < t ? u : t;      // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(t, 63);
+}
+
+// phase stamps of development builds (-DAMP_F6_STAMPS: cycles per phase summed over the waves into ctr[8 ..], turns into ctr[6]); the
+// shipped library has none
+#ifdef AMP_F6_STAMPS
+#define F6_STAMP_DECL unsigned long long f6_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f6_prev = __builtin_amdgcn_s_memtime(); unsigned long long f6_turns = 0
+#define F6_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long f6_n = __builtin_amdgcn_s_memtime(); f6_t[k] += f6_n - f6_prev; f6_prev = f6_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define F6_STAMP_OUT do { if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f6_t[k]); atomicAdd(&ctr[6], f6_turns); } } while (0)
+#define F6_TURN ++f6_turns
+#else
+#define F6_STAMP_DECL
+#define F6_STAMP(k)
+#define F6_STAMP_OUT
+#define F6_TURN
+#endif
 
 struct F6Hdr {                 // a read's header as kept between tiles
     int32_t pos;
@@ -139,13 +200,30 @@ struct F6Hdr {                 // a read's header as kept between tiles
     __device__ bool valid() const { return (lf >> 22) & 1u; }
 };
 
+// The arguments are passed one by one, every pointer followed by a 32-bit value: a struct argument (and a run of adjacent
+// pointers) is loaded as ONE wide register tuple, and a kernel as short of scalar registers as this one then spills and
+// reloads the whole tuple around every use of one field (16 v_readlane for one pointer, several times per tile).
+#define F6_PARAMS \
+    const int32_t *a_pos, int32_t a_min_quality, const uint16_t *a_flag, int32_t a_window, const int32_t *a_tlen, int32_t a_do_trim, \
+    const uint32_t *a_lseq, int32_t a_do_count, const uint32_t *a_cig_off32, int32_t a_ref_len, const uint32_t *a_cig, int32_t a_max_primer_len, \
+    const uint32_t *a_seq_off8, int32_t reads_per_block, const uint8_t *a_seq, int32_t pad0, const uint8_t *a_qual, int32_t pad1, \
+    const int32_t *a_min_start, int32_t pad2, const int32_t *a_max_end, int32_t pad3, \
+    int32_t *a_new_pos, int32_t pad4, uint32_t *a_new_ncig, int32_t pad5, uint32_t *a_new_cig, int32_t pad6, int32_t *a_o_ref_len, int32_t pad7, \
+    uint8_t *a_trim_flags, int32_t pad8, uint8_t *a_status, int32_t pad9, \
+    uint32_t *counts, int32_t pad10, amp_ins_event *a_ev, int32_t pad11, unsigned long long *a_ctr, int32_t pad12, uint32_t *a_ins_at, int32_t pad13, \
+    uint32_t *glist, int32_t pad14, uint32_t *gcnt, int32_t pad15, uint32_t *clist, int32_t pad16, \
+    int64_t a_n_reads, int32_t pad17, uint64_t read_base, int32_t pad18, long long a_ev_cap
+
 template <int W>
 __global__ void __launch_bounds__(F6_WAVES * 64, 2)
-k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
-        uint32_t *clist, int reads_per_block) {
+k_fast6(F6_PARAMS) {
+    const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end};
+    const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
+    const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
+    const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     // separate LDS objects: the compiler only builds alias scopes per LDS variable
     __shared__ uint4 s_q[F6_WAVES][F6_QB / 16];                       // per wave: the tile's qualities, chunk-major
-    __shared__ uint4 s_s[F6_WAVES][F6_SB / 16];                       // per wave: its packed bases, chunk-major; piece-major once masked
+    __shared__ uint4 s_s[F6_WAVES][F6_SB / 16];                       // per wave: the tile's MASKED packed bases, piece-major
     __shared__ uint32_t s_pwin[F6_WAVES][F6_REP * F6_REPW];           // per wave: packed counters
     __shared__ uint32_t s_bwin[F_BPL * F6_BW];                        // the block's window, 32-bit counters: A C G T '-' insertion tally
     __shared__ uint32_t s_ticket, s_gcur, s_n[2];
@@ -169,7 +247,7 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
     // in which the waves' groups of 64 reads arrive: a tile does not rely on it) ------------------------------------------------
     {
         uint32_t *const seg = clist + rb;
-        constexpr int R = 8;                                       // groups of 64 reads whose loads are in flight together
+        constexpr int R = 4;                                       // groups of 64 reads whose loads are in flight together
         for (int64_t g0 = rb + (int64_t)wave * 64; g0 < re; g0 += (int64_t)R * F6_WAVES * 64) {
             uint32_t c0[R], c1[R], ls[R];
 #pragma unroll
@@ -204,7 +282,7 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
     }
     __syncthreads();
     const uint32_t nS = s_n[0], nI = s_n[1];
-    const uint32_t nTS = (nS + 63u) >> 6, nTI = (nI + 63u) >> 6, n_tb = nTS + nTI;
+    const uint32_t nTS = (nS + 63u) >> 6, nTI = (nI + 63u) >> 6, n_tb = (AMP_F6_ABL & 64) ? 0u : nTS + nTI;
 
     const int32_t mq = P.min_quality;
     const uint32_t thr = (uint32_t)mq * (uint32_t)W;                // mq <= 128 (the host sends other runs to the general kernel)
@@ -219,12 +297,11 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
     };
     unsigned long long n_err = 0;
     // lane constants
-    const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F6_REP - 1);
+    const uint32_t rep = ((uint32_t)lane >> 1) & (uint32_t)(F6_REP - 1);
     const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F6_REPW * 4));
     const uint32_t qb_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u8 *)s_q[wave]);
     const uint32_t sb_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u8 *)s_s[wave]);
     const lds_u8 *const qrow = (const lds_u8 *)s_q[wave] + 1024 * (lane >> 5) + 32 * (lane & 31);      // + 2048 (p >> 1) + 16 (p & 1): piece p of the lane's row
-    lds_u8 *const srow16 = (lds_u8 *)s_s[wave] + 16 * lane;          // + 1024 c: raw chunk c (32 bases) of the lane's row
     lds_u8 *const srow8 = (lds_u8 *)s_s[wave] + 8 * lane;            // + 512 p: masked piece p
     const uint32_t one = 1u;
     int32_t pw_base = 0;
@@ -299,11 +376,16 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                      h.c0, h.o8, valid ? ent : (uint32_t)rb};
     };
     struct Cg { uint32_t w[5]; };
-    auto load_cig = [&](const F6Hdr &h) {
+    auto load_cig = [&](const F6Hdr &h, bool indel_tile) {
         Cg c;
         const uint32_t nops = h.nops();
+        c.w[0] = rd.cig[h.c0];
+        c.w[1] = rd.cig[h.c0 + (1u < nops ? 1u : 0u)];                               // (words past the read's own repeat its first)
+        c.w[2] = c.w[3] = c.w[4] = c.w[0];
+        if (indel_tile) {                                                              // (uniform: a tile of simple reads has two ops at most)
 #pragma unroll
-        for (uint32_t k = 0; k < 5u; ++k) c.w[k] = rd.cig[h.c0 + (k < nops ? k : 0u)];        // (words past the read's own repeat its first)
+            for (uint32_t k = 2; k < 5u; ++k) c.w[k] = rd.cig[h.c0 + (k < nops ? k : 0u)];
+        }
         return c;
     };
     // quality rows of a tile: instruction s moves chunk 2 (s >> 1) + (lane & 1) of row 32 (s & 1) + (lane >> 1) to 1024 s + 16 lane
@@ -323,22 +405,29 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             }
             return;
         }
-        dma16_off<0>(qe, qb_w);                dma16_off<0>(qo, qb_w + 1024u);
-        dma16_off<32>(qe, qb_w + 2048u - 32u);   dma16_off<32>(qo, qb_w + 3072u - 32u);
-        dma16_off<64>(qe, qb_w + 4096u - 64u);   dma16_off<64>(qo, qb_w + 5120u - 64u);
-        dma16_off<96>(qe, qb_w + 6144u - 96u);   dma16_off<96>(qo, qb_w + 7168u - 96u);
-        dma16_off<128>(qe, qb_w + 8192u - 128u); dma16_off<128>(qo, qb_w + 9216u - 128u);
-    };
-    // rows of packed bases: instruction c moves chunk c of the lane's own row to 1024 c + 16 lane
-    auto issue_s = [&](const F6Hdr &h) {
-        const uint8_t *sr = rd.seq + (int64_t)h.o8 * 4;
-        if (__ballot((uint64_t)h.o8 + 20u > (uint64_t)q_tot8 + 4u)) {
-            const uint32_t lim = (q_tot8 - h.o8) * 4u;
-#pragma unroll
-            for (int c = 0; c < F6_NP / 2; ++c) dma16_off<0>(sr + ((uint32_t)(16 * c) < lim ? (uint32_t)(16 * c) : lim), sb_w + 1024u * (uint32_t)c);
+        if (AMP_F6_ABL & 256) {
+            const uint8_t *run = rd.qual + (int64_t)__builtin_amdgcn_readfirstlane((int)h.o8) * 8 + lane * 16;
+            dma_q_rows(run, run + 1024, qb_w);          // (timing experiment: ten instructions over one contiguous run; the image is wrong)
             return;
         }
-        dma16_off<0>(sr, sb_w); dma16_off<16>(sr, sb_w + 1008u); dma16_off<32>(sr, sb_w + 2016u); dma16_off<48>(sr, sb_w + 3024u); dma16_off<64>(sr, sb_w + 4032u);
+        dma_q_rows(qe, qo, qb_w);
+    };
+    // rows of packed bases: every lane loads the 80 bytes of its own row into registers (five 16-byte loads).  They are asked for
+    // together with the quality rows, half a tile before they are used, and need no staging buffer of their own: the LDS only
+    // holds the MASKED bases of the tile that is being counted.  (A row within 80 bytes of the end of the buffer: its chunks
+    // behind the rows are fetched from where the rows end.)
+    struct SRaw { uint4 c[F6_NP / 2]; };
+    auto load_s = [&](const F6Hdr &h) {
+        SRaw r;
+        const uint8_t *sr = rd.seq + (int64_t)h.o8 * 4;
+        const uint32_t lim = (q_tot8 - h.o8) * 4u;                      // offsets up to here stay inside (16 bytes of slack)
+#pragma unroll
+        for (int c = 0; c < F6_NP / 2; ++c) {
+            const uint32_t off = (uint32_t)(16 * c) < lim ? (uint32_t)(16 * c) : lim;
+            const uint32_t *g = (const uint32_t *)(sr + off);
+            r.c[c] = make_uint4(g[0], g[1], g[2], g[3]);
+        }
+        return r;
     };
     struct Shape { Bf s; bool ok; int32_t refspan; };
     auto shape_of = [&](const F6Hdr &h, const Cg &c, bool indel_tile) {
@@ -356,54 +445,72 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         if (sh.ok && P.do_trim && in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
         return t;
     };
-    // results of a tile are stored half a tile later (stores and loads retire through one counter)
-    enum : uint32_t { P_STORED = 1u << 24, P_LIST = 1u << 25, P_STATUS_ONLY = 1u << 26 };
-    struct Pend { uint32_t i, slot_lo; int32_t pos, reflen; uint32_t meta, cw0, cw1, cw2, cw3, cw4; };
-    auto store_pending = [&](const Pend &r) {
-        const uint32_t ncig = r.meta & 0xFFu;
-        if (r.meta & P_STORED) {
-            uint32_t *home = out.new_cig + ((size_t)r.slot_lo + 3 * (size_t)r.i);
-            if (ncig > 0u) home[0] = r.cw0;
-            if (ncig > 1u) home[1] = r.cw1;
-            if (ncig > 2u) home[2] = r.cw2;
-            if (ncig > 3u) home[3] = r.cw3;
-            if (ncig > 4u) home[4] = r.cw4;
-            if (out.new_pos) out.new_pos[r.i] = r.pos;
-            if (out.new_ncig) out.new_ncig[r.i] = ncig;
-            if (out.ref_len) out.ref_len[r.i] = r.reflen;
-            if (out.trim_flags) out.trim_flags[r.i] = (uint8_t)(r.meta >> 16);
-            if (out.status) out.status[r.i] = (uint8_t)(r.meta >> 8);
-        }
-        const bool has = (r.meta & P_LIST) != 0;
+    // a read's results (stored behind the trims: pass 1b and pass 2 lie between the stores and the next wait for loads)
+    auto store_results = [&](uint32_t i, uint32_t slot_lo, uint32_t ncig, const uint32_t (&cw)[5], int32_t npos, int32_t reflen, uint32_t flags, uint32_t status) {
+        uint32_t *home = out.new_cig + ((size_t)slot_lo + 3 * (size_t)i);
+        if (ncig > 0u) home[0] = cw[0];
+        if (ncig > 1u) home[1] = cw[1];
+        if (ncig > 2u) home[2] = cw[2];
+        if (ncig > 3u) home[3] = cw[3];
+        if (ncig > 4u) home[4] = cw[4];
+        if (out.new_pos) out.new_pos[i] = npos;
+        if (out.new_ncig) out.new_ncig[i] = ncig;
+        if (out.ref_len) out.ref_len[i] = reflen;
+        if (out.trim_flags) out.trim_flags[i] = (uint8_t)flags;
+        if (out.status) out.status[i] = (uint8_t)status;
+    };
+    // hand-over to the general pass: the block's segment of the list
+    auto push_list = [&](bool has, uint32_t entry) {
         const unsigned long long m = __ballot(has);
         if (m) {
             uint32_t base = 0;
             if (lane == 0) base = __hip_atomic_fetch_add((lds_u32 *)&s_gcur, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (has) glist[(size_t)rb + base + __popcll(m & ((1ull << lane) - 1ull))] = r.i | ((r.meta & P_STATUS_ONLY) ? GL_STATUS_ONLY : 0u);
+            if (has) glist[(size_t)rb + base + __popcll(m & ((1ull << lane) - 1ull))] = entry;
         }
     };
 
-    // ---- prologue of the pipeline ------------------------------------------------------------------------------------------
+#ifndef AMP_F6_STAGGER
+#define AMP_F6_STAGGER 4000
+#endif
+    if (AMP_F6_STAGGER > 0) {
+        // the waves of a block (and the blocks of a launch) start together and take equally long per tile: left alone they ask
+        // for their rows at the same moments and compute at the same moments, so the memory system and the vector pipes take
+        // turns instead of working side by side.  Wave w starts w steps late
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)AMP_F6_STAGGER * (unsigned)wave;
+        while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
+    // ---- prologue of the pipeline.  Across the back edge of the loop only values that have ARRIVED are carried (the two kinds of
+    // turn keep them in different registers: the compiler copies them there, and a copy of a register with a load in flight is
+    // answered with a full wait) ---------------------------------------------------------------------------------------------
     uint32_t tk0 = take_ticket(), tk1 = take_ticket(), tk2 = take_ticket();
-    uint32_t e0 = entry_of(tk0), e1 = entry_of(tk1), e2 = entry_of(tk2);
-    F6Hdr h0 = pack_hdr(load_raw(e0), e0);
-    Raw r1 = load_raw(e1);
-    Cg c0w = load_cig(h0);
-    if (tk0 < n_tb) issue_q(h0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
-    Shape sh0 = shape_of(h0, c0w, tk0 >= nTS);
-    Tabs t0 = load_tabs(h0, sh0);
-    if (tk0 < n_tb) issue_s(h0);
-    F6Hdr h1 = pack_hdr(r1, e1);
-    Raw r2 = load_raw(e2);
-    Pend pend{0u, 0u, 0, 0, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t e2;
+    F6Hdr h0, h1;
+    Cg cw0;
+    SRaw sr0;
+    {
+        const uint32_t e0 = entry_of(tk0), e1 = entry_of(tk1);
+        e2 = entry_of(tk2);
+        h0 = pack_hdr(load_raw(e0), e0);
+        h1 = pack_hdr(load_raw(e1), e1);
+        cw0 = load_cig(h0, tk0 >= nTS);
+        sr0 = load_s(h0);
+        if (tk0 < n_tb) issue_q(h0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+    }
 
+    F6_STAMP_DECL;
     auto turn = [&](auto itag) {
         constexpr bool ITILE = decltype(itag)::value;                   // a tile of indel reads
+        F6_TURN; F6_STAMP(7);
+        uint32_t tk3v = 0;                           // (the ticket of the tile three ahead: asked for now, read behind pass 1b)
+        if (lane == 0) tk3v = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const F6Hdr h = h0;
-        Shape shp = sh0;
+        // ---- requests, first half: this tile's primer-table entries, the header of the tile after the next
+        Shape shp = shape_of(h, cw0, ITILE);
         if (!ITILE) { shp.s.kind = 0; shp.s.k = 0; shp.s.m2 = 0; }      // (constants for the compiler: the closed forms fold)
+        const Tabs tA = load_tabs(h, shp);
+        const Raw r2 = load_raw(e2);
         const int64_t i = (int64_t)h.idx;
         const int32_t pos = h.pos;
         const uint32_t lseq = h.lseq(), flag = h.flag();
@@ -412,10 +519,7 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         // The tile's leftmost read anchors it (the order inside a list is almost, not exactly, the batch's)
         int32_t minpos;
         {
-            int32_t v = h.valid() ? pos : 0x7FFFFFFF;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int32_t u = __shfl_xor(v, o); v = u < v ? u : v; }
-            minpos = __builtin_amdgcn_readfirstlane(v);
+            minpos = wave_min_i32(h.valid() ? pos : 0x7FFFFFFF);
             const int32_t want = (minpos < 16 ? 0 : minpos - 16) & ~15;
             if (pw_tiles >= F6_FLUSH || want < pw_base || want - pw_base >= 32) {
                 if (pw_tiles) fold();
@@ -423,25 +527,28 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             }
             ++pw_tiles;
         }
+        F6_STAMP(0);          // requests, window anchor
         // ---- pass 1a: failing windows of the whole read, pieces in their natural order (the quality rows were waited for at
         // the end of the previous turn) --------------------------------------------------------------------------------------
         uint32_t F[F6_NP / 2];
         uint32_t fb;
         {
-            uint4 q;
-            { const amp_u32x4 a = *(const lds_u32x4 *)(qrow); q = make_uint4(a.x, a.y, a.z, a.w); }
-            fb = q.x & 0xFFu;
+            auto piece = [&](int k) -> uint4 { const amp_u32x4 a = *(const lds_u32x4 *)(qrow + 2048 * (k >> 1) + 16 * (k & 1)); return make_uint4(a.x, a.y, a.z, a.w); };
+            uint4 q0 = piece(0), q1 = piece(1), q2 = piece(2);          // (three pieces on their way: a round trip to the LDS takes longer than a piece's arithmetic)
+            fb = q0.x & 0xFFu;
 #pragma unroll
             for (int k = 0; k < F6_NP; ++k) {
-                uint4 nq = q;
-                if (k + 1 < F6_NP) { const amp_u32x4 a = *(const lds_u32x4 *)(qrow + 2048 * ((k + 1) >> 1) + 16 * ((k + 1) & 1)); nq = make_uint4(a.x, a.y, a.z, a.w); }
-                const uint32_t f16 = P.do_trim ? f6_fail16<W>(q, nq, thr, nthr) : 0u;
+                uint4 q3 = q2;
+                if (k + 3 < F6_NP) q3 = piece(k + 3);
+                const uint32_t f16 = (P.do_trim && !(AMP_F6_ABL & 4)) ? f6_fail16<W>(q0, q1, thr, nthr) : (q0.x & 1u);
                 if (k & 1) F[k >> 1] |= f16 << 16; else F[k >> 1] = f16;
-                q = nq;
+                q0 = q1; q1 = q2; q2 = q3;
+                __builtin_amdgcn_sched_barrier(0);          // one piece at a time: interleaving them costs registers
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the table entries and the rows of packed bases requested at the end of the previous turn
-        const Tabs tA = t0;
+        F6_STAMP(1);          // pass 1a
+        // (no wait here: the clips below wait for the two table entries only -- they are the oldest requests of the turn -- and run while
+        //  the rows of packed bases are still on their way)
         // ---- primer clips in closed form (A:450-558) ---------------------------------------------------------------------
         Bf s = shp.s;
         const bool shaped = shp.ok;
@@ -449,13 +556,13 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         const int32_t q_ins = s.kind ? s.a + s.m1 : 0;                 // query index of the first inserted base / of the base behind the deletion
         TrimState ts{pos, 1, 0u, 0};
         {
-            const bool trim = shaped & (P.do_trim != 0), use = trim & in_ref;
+            const bool trim = shaped & (P.do_trim != 0) & !(AMP_F6_ABL & 128), use = trim & in_ref;
             ts.err = (trim & !in_ref) ? AMP_RS_INDEX_REF : 0;
             int32_t p2 = pos; uint32_t f2 = 0u;
             const Bf sp = bf_trim_primers(s, p2, f2, flag, h.isize_flag(), (int32_t)lseq, tA.L, tA.R);
             s = bf_pick(use, sp, s); ts.pos = use ? p2 : pos; ts.flags = use ? f2 : 0u;
         }
-        const bool scan = shaped & (P.do_trim != 0) & (ts.err == 0) & !s.punt;
+        const bool scan = shaped & (P.do_trim != 0) & (ts.err == 0) & !s.punt & !(AMP_F6_ABL & 128);
         int32_t lo, qlen;
         bf_quality_window(s, (int32_t)lseq, lo, qlen);
         lo = scan ? lo : 0; qlen = scan ? qlen : 0;
@@ -548,30 +655,43 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         // such a read is counted base by base
         bool want_status = false;
         bool slow_all = counted && (uint32_t)end_pos > G;
+        F6_STAMP(3);          // clips, results
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the header of the tile after the next, requested at the top of the turn
+        F6_STAMP(2);          // wait
         // ---- pass 1b: the codes of the low-quality bases become zero; the masked pieces go back piece-major -------------------
         uint4 iq16 = make_uint4(0u, 0u, 0u, 0u);
         const int32_t g_ins = q_ins & ~7;
         if (ITILE) iq16 = row16(g_ins);
         uint32_t zacc = 0;                           // a code 0 ('=') under a good quality: bit 3 of some nibble (pass 2 cannot tell it from a masked base)
+        {
+            struct Ch { amp_u32x4 qa, qb, sq; };
+            auto chunk = [&](int c) { return Ch{*(const lds_u32x4 *)(qrow + 2048 * c), *(const lds_u32x4 *)(qrow + 2048 * c + 16), amp_u32x4{sr0.c[c].x, sr0.c[c].y, sr0.c[c].z, sr0.c[c].w}}; };
+            Ch c0 = chunk(0), c1 = chunk(1);                      // (two chunks on their way while one is worked on)
 #pragma unroll
-        for (int c = 0; c < F6_NP / 2; ++c) {
-            const amp_u32x4 qa = *(const lds_u32x4 *)(qrow + 2048 * c), qb = *(const lds_u32x4 *)(qrow + 2048 * c + 16);
-            const amp_u32x4 sq = *(const lds_u32x4 *)(srow16 + 1024 * c);
-            const uint32_t k0 = f6_keep8(f6_ok80(qa.x, mqb), f6_ok80(qa.y, mqb)), k1 = f6_keep8(f6_ok80(qa.z, mqb), f6_ok80(qa.w, mqb));
-            const uint32_t k2 = f6_keep8(f6_ok80(qb.x, mqb), f6_ok80(qb.y, mqb)), k3 = f6_keep8(f6_ok80(qb.z, mqb), f6_ok80(qb.w, mqb));
-            { const uint32_t w0 = sq.x | ~k0, w1 = sq.y | ~k1, w2 = sq.z | ~k2, w3 = sq.w | ~k3;      // has-zero-nibble over the kept codes
-              zacc |= ((w0 - 0x11111111u) & ~w0) | ((w1 - 0x11111111u) & ~w1) | ((w2 - 0x11111111u) & ~w2) | ((w3 - 0x11111111u) & ~w3); }
-            *(lds_u32x2 *)(srow8 + 1024 * c) = amp_u32x2{sq.x & k0, sq.y & k1};
-            *(lds_u32x2 *)(srow8 + 1024 * c + 512) = amp_u32x2{sq.z & k2, sq.w & k3};
+            for (int c = 0; c < F6_NP / 2; ++c) {
+                Ch c2 = c1;
+                if (c + 2 < F6_NP / 2) c2 = chunk(c + 2);
+                const amp_u32x4 qa = c0.qa, qb = c0.qb, sq = c0.sq;
+                const uint32_t k0 = (AMP_F6_ABL & 8) ? qa.x : f6_keep8(f6_ok80(qa.x, mqb), f6_ok80(qa.y, mqb)), k1 = (AMP_F6_ABL & 8) ? qa.z : f6_keep8(f6_ok80(qa.z, mqb), f6_ok80(qa.w, mqb));
+                const uint32_t k2 = (AMP_F6_ABL & 8) ? qb.x : f6_keep8(f6_ok80(qb.x, mqb), f6_ok80(qb.y, mqb)), k3 = (AMP_F6_ABL & 8) ? qb.z : f6_keep8(f6_ok80(qb.z, mqb), f6_ok80(qb.w, mqb));
+                { const uint32_t w0 = sq.x | ~k0, w1 = sq.y | ~k1, w2 = sq.z | ~k2, w3 = sq.w | ~k3;      // has-zero-nibble over the kept codes
+                  zacc |= ((w0 - 0x11111111u) & ~w0) | ((w1 - 0x11111111u) & ~w1) | ((w2 - 0x11111111u) & ~w2) | ((w3 - 0x11111111u) & ~w3); }
+                // (the reads of the chunks ahead are in front of these writes in the queue; a chunk's writes stay inside its own 1 KB)
+                *(lds_u32x2 *)(srow8 + 1024 * c) = amp_u32x2{sq.x & k0, sq.y & k1};
+                *(lds_u32x2 *)(srow8 + 1024 * c + 512) = amp_u32x2{sq.z & k2, sq.w & k3};
+                c0 = c1; c1 = c2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         zacc &= 0x88888888u;
         wave_sync();                                 // both buffers have been read: the quality image is free
-        // ---- requests, first half: the next tile's CIGAR words and quality rows, the header of the tile behind it, the list
-        // entries of the one behind that; and this turn's stores of the previous tile's results ---------------------------------
-        store_pending(pend);
-        const uint32_t tk3 = take_ticket();
-        const Cg c1w = load_cig(h1);
-        if (tk1 < n_tb) issue_q(h1);
+        F6_STAMP(4);          // pass 1b
+        // the read's results (pass 2 lies between these stores and the next wait for loads)
+        if (stored && !(AMP_F6_ABL & 32)) store_results((uint32_t)i, h.c0, ncig, cw, ts.pos, reflen, ts.err ? 0u : ts.flags, (uint32_t)ts.err);
+        // ---- requests, second half: the next tile's CIGAR words and quality rows, the list entries of the tile three ahead --------
+        const uint32_t tk3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk3v);
+        const Cg c1w = load_cig(h1, tk1 >= nTS);
+        if (tk1 < n_tb && !(AMP_F6_ABL & 16)) issue_q(h1);
         const F6Hdr h2 = pack_hdr(r2, e2);
         const uint32_t e3 = entry_of(tk3);
         // ---- the ends of the counted ranges: the pieces that hold them are masked to the range ----------------------------------
@@ -590,8 +710,17 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 }
                 if (on) *w = amp_u32x2{x.x & k.x, x.y & k.y};
             };
-            mask_piece(qa1 >> 4, any1);
-            mask_piece((qb1 - 1) >> 4, any1);
+            if (ITILE) { mask_piece(qa1 >> 4, any1); mask_piece((qb1 - 1) >> 4, any1); }
+            else {
+                // (both pieces read before either is written: two round trips become one; the same piece twice gets the same mask twice)
+                const int32_t pa = any1 ? qa1 >> 4 : 0, pb = any1 ? (qb1 - 1) >> 4 : 0;
+                lds_u32x2 *wa = (lds_u32x2 *)(srow8 + 512 * pa), *wb2 = (lds_u32x2 *)(srow8 + 512 * pb);
+                const amp_u32x2 xa = *wa, xb = *wb2;
+                const int32_t ja = 16 * pa, jb2 = 16 * pb;
+                const uint2 ka = f6_range_nibbles(qa1 - ja < 0 ? 0 : qa1 - ja, qb1 - ja > 16 ? 16 : qb1 - ja);
+                const uint2 kb2 = f6_range_nibbles(qa1 - jb2 < 0 ? 0 : qa1 - jb2, qb1 - jb2 > 16 ? 16 : qb1 - jb2);
+                if (any1) { *wa = amp_u32x2{xa.x & ka.x, xa.y & ka.y}; *wb2 = amp_u32x2{xb.x & kb2.x, xb.y & kb2.y}; }
+            }
             if (ITILE) {
                 mask_piece(qa2 >> 4, any2);
                 mask_piece((qb2 - 1) >> 4, any2);
@@ -667,23 +796,24 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
             }
         }
         wave_sync();
+        // (the next tile's packed bases: asked for here, behind the register-hungry part of the turn; pass 2 covers the wait)
+        SRaw sr1 = sr0;
+        if (!(AMP_F6_ABL & 16)) sr1 = load_s(h1);
+        F6_STAMP(5);          // requests, range ends, (indel tiles: deletions, events)
         // ---- pass 2: the masked codes into the wave's packed window.  A tile is counted in passes: every pass takes the lanes
         // whose counted positions lie inside the window, then the window is folded and anchored at the leftmost lane left.
         // Lane l works on piece (k + l) mod np in step k: the lanes of a pile of reads do not add to one address at a time -------
         const uint32_t np = (lseq + 15u) >> 4;
         const uint32_t npc = np < 1u ? 1u : (np > (uint32_t)F6_NP ? (uint32_t)F6_NP : np);
-        const uint32_t rot = (uint32_t)lane % npc;
+        const uint32_t rot = (uint32_t)lane - npc * (((uint32_t)lane * ((1023u + npc) / npc)) >> 10);      // lane % npc (exact for lane < 64, npc <= 10)
         uint32_t badacc = 0;
         // (slow_all: also a read no window position takes -- the first / last 16 positions of the reference)
-        bool todo = counted && !slow_all;
+        bool todo = counted && !slow_all && !(AMP_F6_ABL & 2);
         for (bool first_pass = true;; first_pass = false) {
             const unsigned long long tm = __ballot(todo);
             if (!tm) break;
             // (the leftmost of the lanes that are left)
-            int32_t v = todo ? ts.pos : 0x7FFFFFFF;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int32_t u = __shfl_xor(v, o); v = u < v ? u : v; }
-            const int32_t lead_pos = __builtin_amdgcn_readfirstlane(v);
+            const int32_t lead_pos = wave_min_i32(todo ? ts.pos : 0x7FFFFFFF);
             if (!first_pass || lead_pos - pw_base < 16) {
                 if (!first_pass || pw_tiles > 1) fold();
                 set_window(lead_pos); pw_tiles = 1;
@@ -700,24 +830,31 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 const uint2 mb = (has_b && now) ? bsq : make_uint2(0u, 0u);
                 f6_count16(mb, wrep + (uint32_t)d0 * 4u, one, badacc);
             }
+            // All ten pieces are read BEFORE the first add: the adds are issued by inline assembly, the compiler does not count them,
+            // and its wait for a read that was issued behind a piece's adds would drain those adds too (the LDS returns in order) --
+            // the wave would stand still until its own 16 atomics have executed, ten times per tile
+            auto piece_of = [&](int k) -> uint32_t { uint32_t p = (uint32_t)k + rot; p = p >= npc ? p - npc : p; return (uint32_t)k < npc ? p : 0u; };
+            amp_u32x2 xs[F6_NP];
+#pragma unroll
+            for (int k = 0; k < F6_NP; ++k) xs[k] = *(const lds_u32x2 *)(srow8 + 512 * piece_of(k));
 #pragma unroll
             for (int k = 0; k < F6_NP; ++k) {
-                uint32_t p = (uint32_t)k + rot;
-                p = p >= npc ? p - npc : p;
+                const uint32_t p = piece_of(k);
                 const bool slot = (uint32_t)k < npc;
                 const int32_t j0 = (int32_t)(p * 16u);
-                const amp_u32x2 x = *(const lds_u32x2 *)(srow8 + 512 * (slot ? p : 0u));
+                const amp_u32x2 x = xs[k];
                 const bool second = ITILE && (j0 >= b1 || b1 <= a1);      // a piece behind the first range belongs to the second
                 const bool in = slot && (second ? (j0 < b2 && j0 + 16 > a2 && a2 < b2) : (j0 < b1 && j0 + 16 > a1 && a1 < b1));
                 int32_t d0 = (second ? dbase2 : dbase1) + j0;
                 d0 = d0 < 0 ? 0 : (d0 > F6_PW - 16 ? F6_PW - 16 : d0);
                 const uint2 m = in ? make_uint2(x.x, x.y) : make_uint2(0u, 0u);
                 f6_count16(m, wrep + (uint32_t)d0 * 4u, one, badacc);
+                __builtin_amdgcn_sched_barrier(0);
             }
             todo = todo && !now && !slow_all;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wave_sync();                                 // the base image has been read: free
+        // (the base image was read before the first add: free.  The adds drain while the next turn starts)
+        F6_STAMP(6);          // pass 2
         // ---- careful loop (rare): the reads with a counted code outside A C G T (N calls are counted here, anything else wants
         // its exact status), and the reads no window took --------------------------------------------------------------------------
         want_status = want_status || bad_extra;
@@ -741,28 +878,17 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
                 if (two) careful(qa2, qb2, pos2);
             }
         }
-        // ---- results and hand-over to the general pass: kept for the next turn ---------------------------------------------------
-        {
-            uint32_t meta = ncig | ((uint32_t)ts.err << 8) | ((ts.err ? 0u : ts.flags) << 16) | (stored ? P_STORED : 0u);
-            if (general) meta |= P_LIST;
-            else if (stored && !ts.err && P.do_count && want_status) meta |= P_LIST | P_STATUS_ONLY;      // a base could not be counted: exact status wanted
-            pend = Pend{(uint32_t)i, h.c0, ts.pos, reflen, meta, cw[0], cw[1], cw[2], cw[3], cw[4]};
-        }
-        // ---- requests, second half: everything asked for behind pass 1b has arrived; the next tile's table entries and rows of
-        // packed bases ------------------------------------------------------------------------------------------------------------
+        // ---- hand-over to the general pass -------------------------------------------------------------------------------------
+        push_list(general || (stored && !ts.err && P.do_count && want_status),
+                  (uint32_t)i | (general ? 0u : GL_STATUS_ONLY));          // (status only: a base could not be counted, exact status wanted)
+        // ---- everything asked for behind pass 1b has arrived ----------------------------------------------------------------------
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         tk0 = tk1; tk1 = tk2; tk2 = tk3;
-        h0 = h1; h1 = h2;
-        e2 = e3;
-        r2 = load_raw(e3);
-        sh0 = shape_of(h0, c1w, tk0 >= nTS);
-        t0 = load_tabs(h0, sh0);
-        if (tk0 < n_tb) issue_s(h0);
+        h0 = h1; h1 = h2; cw0 = c1w; e2 = e3; sr0 = sr1;
     };
     while (tk0 < n_tb) {
         if (tk0 >= nTS) turn(std::true_type{}); else turn(std::false_type{});
     }
-    store_pending(pend);
     pad_events();
     if (n_tb) fold();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (asm adds into the block's window: deletions, insertion tally, careful loop)
@@ -780,6 +906,7 @@ k_fast6(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         }
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
+    F6_STAMP_OUT;
     if (tid == 0) gcnt[blockIdx.x] = s_gcur;
 }
 
@@ -794,16 +921,20 @@ static inline int fast6_launch(const KParams &P, const amp_dev_reads &rd, uint64
                                const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, uint32_t *clist, const FastGrid &fg, hipStream_t stream) {
     const unsigned g = (unsigned)fg.grid, t = F6_WAVES * 64;
     const int rpb = (int)fg.rpb;
+#define F6_GO(w) k_fast6<w><<<g, t, 0, stream>>>(rd.pos, P.min_quality, rd.flag, P.window, rd.tlen, P.do_trim, rd.lseq, P.do_count, rd.cig_off32, P.ref_len, rd.cig, \
+        P.max_primer_len, rd.seq_off8, rpb, rd.seq, 0, rd.qual, 0, P.min_start, 0, P.max_end, 0, out.new_pos, 0, out.new_ncig, 0, out.new_cig, 0, out.ref_len, 0, \
+        out.trim_flags, 0, out.status, 0, counts, 0, eb.ev, 0, eb.ctr, 0, eb.ins_at, 0, glist, 0, gcnt, 0, clist, 0, rd.n_reads, 0, read_base, 0, eb.cap)
     switch (P.window) {
-        case 1: k_fast6<1><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 2: k_fast6<2><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 3: k_fast6<3><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 4: k_fast6<4><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 5: k_fast6<5><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 6: k_fast6<6><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        case 7: k_fast6<7><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
-        default: k_fast6<8><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, clist, rpb); break;
+        case 1: F6_GO(1); break;
+        case 2: F6_GO(2); break;
+        case 3: F6_GO(3); break;
+        case 4: F6_GO(4); break;
+        case 5: F6_GO(5); break;
+        case 6: F6_GO(6); break;
+        case 7: F6_GO(7); break;
+        default: F6_GO(8); break;
     }
+#undef F6_GO
     return (int)hipGetLastError();
 }
 

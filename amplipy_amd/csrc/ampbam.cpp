@@ -564,7 +564,7 @@ bool index_records(const uint8_t *d, size_t avail, size_t o0, size_t lim, int32_
             }
             if (!found) { g.end = hi; g.stopped = true; return; }        // (stitching walks this stretch serially)
         }
-        g.off.reserve((hi - o) / 200 + 16); g.info.reserve((hi - o) / 200 + 16);
+        if (hi > o) { g.off.reserve((hi - o) / 200 + 16); g.info.reserve((hi - o) / 200 + 16); }
         while (o < hi) {
             uint64_t info; size_t next;
             if (!step(o, &info, &next, &g.bad)) { g.stopped = true; break; }
@@ -603,6 +603,10 @@ bool index_records(const uint8_t *d, size_t avail, size_t o0, size_t lim, int32_
 }
 
 int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, ampbam_file **out) {
+    return ampbam_open_range_at(path, n_threads, part, n_parts, UINT64_MAX, out);
+}
+
+int ampbam_open_range_at(const char *path, int n_threads, int part, int n_parts, uint64_t first_hint, ampbam_file **out) {
     if (!path || !out || n_parts < 1 || part < 0 || part >= n_parts) return AMPBAM_EINVAL;
     *out = nullptr;
     MappedFile raw;
@@ -697,8 +701,26 @@ int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, am
     const size_t lim = (size_t)(end_off - f->img_base);
     try {
         f->rec_off.reserve(lim / 200 + 16); f->rec_info.reserve(lim / 200 + 16);
-        if (part == 0) {
+        if (first_hint != UINT64_MAX && part > 0) {
+            // the caller knows where this part's first record starts (the part before it ended there): no guessing
+            if (first_hint < f->img_base) return fail(AMPBAM_EINVAL);
+            if (first_hint >= end_off) {                   // no record starts in this part
+                f->part_first = f->part_end = first_hint;
+                f->rec_off.push_back(0);
+                *out = f;
+                return AMPBAM_OK;
+            }
+            o = (size_t)(first_hint - f->img_base);
+            f->part_first = first_hint;
+            if (!index_records(f->data.data(), f->data.size() - 16, o, lim, n_ref, f->n_threads, f->rec_off, f->rec_info, &o)) return fail(AMPBAM_EFORMAT);
+        } else if (part == 0) {
             if (hdr_end < f->img_base) return fail(AMPBAM_EFORMAT);
+            if (hdr_end >= end_off) {                      // the header (text + reference dictionary) fills the part's blocks and more: no record starts here
+                f->part_first = f->part_end = hdr_end;
+                f->rec_off.push_back(0);
+                *out = f;
+                return AMPBAM_OK;
+            }
             o = hdr_end - (size_t)f->img_base;
             f->part_first = f->img_base + o;
             if (!index_records(f->data.data(), f->data.size() - 16, o, lim, n_ref, f->n_threads, f->rec_off, f->rec_info, &o)) return fail(AMPBAM_EFORMAT);
@@ -710,7 +732,8 @@ int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, am
             const size_t avail = f->data.size() - 16;
             const size_t limit = std::min<size_t>(avail, lim);
             bool found = false;
-            for (size_t cand = 0; cand < limit && !found; ++cand) {
+            const size_t cand0 = hdr_end > f->img_base ? (size_t)(hdr_end - f->img_base) : 0;      // (a header that reaches into this part)
+            for (size_t cand = cand0; cand < limit && !found; ++cand) {
                 size_t at = cand, nx = 0;
                 int chain = 0;
                 while (chain < 64 && at + 36 <= avail && plausible_record(f->data.data(), avail, at, n_ref, &nx)) { at = nx; ++chain; }

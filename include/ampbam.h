@@ -65,6 +65,12 @@ int ampbam_open(const char *path, int n_threads, ampbam_file **out);
  * start where part k ended (a mismatch: fall back to ampbam_open).  Record numbers of such a file count from the part's
  * first record; header text and references are those of the whole file.  n_parts == 1 is ampbam_open. */
 int ampbam_open_range(const char *path, int n_threads, int part, int n_parts, ampbam_file **out);
+/* The same when the caller KNOWS where the part's first record starts -- the inflated offset at which the part before it ended
+ * (ampbam_part_range of that part): nothing is guessed, which is how one process walks a file piece by piece (only a rank's
+ * first piece needs the heuristic above).  first_hint == UINT64_MAX: ampbam_open_range.  A hint at or behind the part's last
+ * block means no record starts in the part: an empty part whose range is (hint, hint).  AMPBAM_EINVAL for a hint in front of
+ * the part's first block, AMPBAM_EFORMAT when no chain of records runs from the hint to the part's end. */
+int ampbam_open_range_at(const char *path, int n_threads, int part, int n_parts, uint64_t first_hint, ampbam_file **out);
 /* Offsets in the file's INFLATED stream of the part's first record and of the byte behind its last record (equal for a
  * part without records; 0 / 0 ... for a file opened with ampbam_open: header end / stream end are not tracked there). */
 int ampbam_part_range(const ampbam_file *f, uint64_t *first, uint64_t *end);

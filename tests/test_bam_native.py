@@ -320,3 +320,75 @@ def test_record_index_ignores_decoy_records(tmp_path):
         total += f.n_records
         f.close()
     assert total == len(recs)
+
+
+def test_piece_walk_does_not_guess_record_starts(tmp_path, monkeypatch):
+    """A decoy that ENDS where its host record ends -- a trailing B:C tag whose bytes are a run of plausible records -- rejoins the
+    true chain, so a piece that guessed its first record inside the tag would look right to every local check and only fail
+    against its neighbour (one record too many).  One process walking a file never guesses: every piece after the first is
+    opened at the offset where the piece before it ended (ampbam_open_range_at).  The walk over many small pieces gives the
+    whole file's rows; the hinted open of every part equals the part's range; and a header longer than the first parts'
+    blocks leaves those parts empty instead of failing."""
+    import struct
+    from amplipy_amd import amplipy
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    segs = synth.make_mixed_segments(g, amps, 6000, seed=11)
+    hdr = bamio.Header("@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:SYN_REF\tLN:%d\n" % g.size, [("SYN_REF", int(g.size))])
+    fake = struct.pack("<iiiBBHHHIiii", 34, 0, 5, 2, 60, 4680, 0, 0, 0, -1, -1, 0) + b"A\0"
+    tag = b"zzBC" + struct.pack("<I", 80 * len(fake)) + fake * 80            # aux array of 80 plausible records: the record ends with it
+    recs = []
+    for i, s in enumerate(segs):
+        r = bamio.Rec("r%d" % i, s.flag, 0, s.reference_start, 60, s.cigartuples, 0, s.reference_start, s.template_length,
+                      s.query_sequence, bytes(s.query_qualities))
+        if i % 97 == 13:
+            r.aux_bam = tag
+        recs.append(r)
+    bam = str(tmp_path / "t.bam")
+    w = bamio.AlignmentWriter(bam, "wb", hdr)
+    for r in recs:
+        w.write(r)
+    w.close()
+    whole = bam_native.BamFile(bam)
+    assert whole.n_records == len(recs)
+    wb, _ = whole.decode(0, whole.n_records, copy=True)
+    whole.close()
+    # the walk of run_amplipy's input: many pieces, each told where it starts
+    monkeypatch.setenv("AMPLIPY_PART_BYTES", "20000")
+    src = amplipy.NativeInput(bam, 0, 1)
+    assert src.n_parts > 20
+    rows, n = [], 0
+    for piece in src:
+        n += piece.n_records
+        if piece.n_records:
+            rows.append(piece.decode(0, piece.n_records, copy=True)[0])
+        piece.close()
+    assert n == len(recs)
+    assert np.array_equal(np.concatenate([r.pos for r in rows]), wb.pos) and np.array_equal(np.concatenate([r.qual for r in rows]), wb.qual)
+    # hinted opens agree with the chain of part ranges; a wrong hint is refused or runs into garbage, never accepted silently as another range
+    n_parts = 9
+    end = None
+    total = 0
+    for k in range(n_parts):
+        f = bam_native.BamFile(bam, part=k, n_parts=n_parts, first_hint=end)
+        a, b = f.part_range()
+        assert end is None or a == end
+        end = b
+        total += f.n_records
+        f.close()
+    assert total == len(recs)
+    # a header that is longer than the first parts
+    big = bamio.Header("@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:c%06d\tLN:1000\n" % i for i in range(60000)) ,
+                       [("c%06d" % i, 1000) for i in range(60000)])
+    bam2 = str(tmp_path / "h.bam")
+    w = bamio.AlignmentWriter(bam2, "wb", big)
+    for r in recs[:500]:
+        w.write(r)
+    w.close()
+    for n_parts in (1, 4, 16):
+        end = None; total = 0
+        for k in range(n_parts):
+            f = bam_native.BamFile(bam2, part=k, n_parts=n_parts, first_hint=end)
+            end = f.part_range()[1]
+            total += f.n_records
+            f.close()
+        assert total == 500, n_parts

@@ -30,6 +30,11 @@ for it in range(a.iters):
     e.reset(); e.process_device(rd, 0, dev_out); e.sync(); ms.append(e.last_kernel_ms())
 print("variant %d window %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.window, a.depth, n), ["%.3f/%.3f" % m for m in ms])
 if not os.environ.get("AMP_STAMPS"): print("general-pass reads of the last launch:", int(e.debug_counters()[7]))
+if os.environ.get("AMP_F6_STAMPS"):
+    dc = e.debug_counters(); turns = max(int(dc[6]), 1)
+    names = ["requests+anchor", "pass 1a", "wait", "clips+results", "pass 1b", "requests+range ends", "pass 2", "tail+end wait"]
+    tot = float(sum(int(dc[8 + k]) for k in range(8)))
+    print("k_fast6 stamps (last launch): turns %d; shader cycles per turn: %s | total %.0f" % (turns, ", ".join("%s %.0f" % (names[k], int(dc[8 + k]) / turns) for k in range(8)), tot / turns))
 if os.environ.get("AMP_STAMPS") not in (None, "", "0") and not os.environ.get("AMPLIHIP_PHASES"):
     dc = e.debug_counters()
     tot = float(sum(int(x) for x in dc[9:15])) or 1.0
