@@ -320,12 +320,18 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
     G = len(ref_seq)
     eng = lib.Engine(G, device=device)
     table = None
+    final_trimmed_fn = None
     if dist is not None:
         import torch
         torch.cuda.set_device(device)
         table = torch.zeros(G * 7, dtype=torch.int32, device="cuda:%d" % device)   # counts + insertion tally
         eng.bind_counts(table.data_ptr())
         if run_trim and trimmed_reads_fn is not None and world > 1:
+            # every rank writes the trimmed reads of its share to a file of its own; rank 0 joins them into the ONE file the
+            # caller asked for once every rank is done (BGZF members concatenate: bam_native.stitch_bam_parts)
+            if rank == 0 and trimmed_reads_fn.lower() != "stdout" and isfile(trimmed_reads_fn):
+                error("File already exists: %s" % trimmed_reads_fn)
+            final_trimmed_fn = trimmed_reads_fn
             root, ext = os.path.splitext(trimmed_reads_fn)
             trimmed_reads_fn = "%s.part%d%s" % (root, rank, ext)
     if primer_fn is not None:
@@ -385,6 +391,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         del pending[:]
 
     n_seen = 0                           # records this rank has gone through (all of them when there is one rank)
+    n_bases = 0                          # ... and their bases (the measure the shares of a multi-rank run should be equal in: SURVEY 8e)
     if native is not None:
         # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
         # re-encodes the kept ones; no per-read Python object exists on this path.  The file is walked piece by piece:
@@ -424,6 +431,7 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                     s_i = n_seen - 1
                     if batch.n == 0:
                         continue
+                    n_bases += int(batch.lseq.sum(dtype=np.int64))
                     res = eng.process(batch, read_base=read_base)
                     bad = np.nonzero(res.status)[0]
                     if wq is not None:
@@ -500,6 +508,21 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
             if rank_error is not None:
                 raise rank_error
             raise RuntimeError(trouble)
+        shares = parallel.gather_objects(dist, rank, world, (n_seen, n_bases))
+        if rank == 0 and native is not None:
+            # the file is cut by compressed bytes (ampbam_open_range): what that gave every rank, in records and in bases
+            tot = max(sum(b_ for _, b_ in shares), 1)
+            print_log("Shares of the %d ranks: records %s; bases %s (%s %% of the job)" % (world, [r_ for r_, _ in shares], [b_ for _, b_ in shares],
+                                                                                        ", ".join("%.1f" % (100.0 * b_ / tot) for _, b_ in shares)))
+        if final_trimmed_fn is not None and native is not None and native[1] is not None:
+            # the ranks' files (all closed by now: the writer threads were joined above) become the one trimmed BAM
+            parts = parallel.gather_objects(dist, rank, world, (native[1].path, native[1].header_bytes))
+            if rank == 0:
+                from . import bam_native
+                bam_native.stitch_bam_parts(final_trimmed_fn, parts)
+                for path, _ in parts:
+                    os.remove(path)
+                print_log("Trimmed reads of %d ranks joined: %s" % (world, final_trimmed_fn))
 
     try:
       if do_count:

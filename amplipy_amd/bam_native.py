@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libampbam.so")
 EXPORTS = [
     "ampbam_version", "ampbam_strerror", "ampbam_open", "ampbam_close", "ampbam_last_error", "ampbam_n_records",
     "ampbam_header_text", "ampbam_n_refs", "ampbam_ref", "ampbam_decode", "ampbam_writer_open", "ampbam_write_rows",
-    "ampbam_writer_close", "ampbam_open_range", "ampbam_open_range_at", "ampbam_part_range", "ampbam_crc32", "ampbam_inflate_raw",
+    "ampbam_writer_close", "ampbam_writer_header_bytes", "ampbam_write_batch", "ampbam_open_range", "ampbam_open_range_at", "ampbam_part_range", "ampbam_crc32", "ampbam_inflate_raw",
 ]
 _LIB = None
 
@@ -136,6 +136,9 @@ class BamWriter:
         if rc:
             raise AmpBamError("%s: %s" % (path, self.L.ampbam_strerror(rc).decode()))
         self.h = h
+        self.L.ampbam_writer_header_bytes.restype = C.c_int64
+        self.path = path
+        self.header_bytes = int(self.L.ampbam_writer_header_bytes(h))      # the header has BGZF blocks of its own: their size in the file
 
     def write_rows(self, src, src_index, keep, new_pos, new_ncig, new_cig_off, new_cig):
         """Rows of a batch decoded from ``src`` (the input file, or the piece of it the batch came from; None: the file the
@@ -151,9 +154,44 @@ class BamWriter:
         if rc:
             raise AmpBamError("write: %s" % self.L.ampbam_strerror(rc).decode())
 
+    def write_batch(self, b, name_base=0):
+        """The rows of a packed ReadBatch as NEW records named r<name_base + row> (ampbam_write_batch: files made from synthetic
+        reads; no aux fields, mate on the read's own position)."""
+        arr = [np.ascontiguousarray(x, t) for x, t in ((b.pos, np.int32), (b.flag, np.uint16), (b.tlen, np.int32), (b.lseq, np.uint32),
+                                                        (b.cig_off, np.uint64), (b.cig, np.uint32), (b.seq_off, np.uint64), (b.seq, np.uint8), (b.qual, np.uint8))]
+        rc = self.L.ampbam_write_batch(self.h, C.c_int64(b.n), *[C.c_void_p(a.ctypes.data) for a in arr], C.c_uint64(name_base))
+        if rc:
+            raise AmpBamError("write_batch: %s" % self.L.ampbam_strerror(rc).decode())
+
     def close(self):
         if self.h:
             h, self.h = self.h, None
             rc = self.L.ampbam_writer_close(h)
             if rc:
                 raise AmpBamError("close: %s" % self.L.ampbam_strerror(rc).decode())
+
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def stitch_bam_parts(out_path, parts):
+    """The ONE trimmed BAM of a multi-rank run (AmpliPy.py:326-356, :911 write one file): ``parts`` = [(path, header_bytes)] in rank
+    order, each a complete BAM written by BamWriter with the same header.  BGZF members concatenate, so the result is part 0
+    without its EOF block, the later parts without their header blocks and EOF blocks, and one EOF block."""
+    with open(out_path, "wb") as out:
+        for k, (path, header_bytes) in enumerate(parts):
+            size = os.path.getsize(path)
+            with open(path, "rb") as f:
+                f.seek(size - len(BGZF_EOF))
+                if f.read() != BGZF_EOF:
+                    raise AmpBamError("%s does not end with a BGZF EOF block" % path)
+                start = 0 if k == 0 else int(header_bytes)
+                f.seek(start)
+                left = size - len(BGZF_EOF) - start
+                while left > 0:
+                    buf = f.read(min(left, 1 << 24))
+                    if not buf:
+                        raise AmpBamError("%s: short read" % path)
+                    out.write(buf)
+                    left -= len(buf)
+        out.write(BGZF_EOF)

@@ -317,6 +317,7 @@ struct ampbam_writer {
     int level = -1, n_threads = 1;
     Bytes pend;                             // uncompressed bytes not yet written (no zero fill on growth)
     Bytes comp;                             // compressed blocks of one flush, at a fixed stride
+    int64_t header_bytes = 0;               // compressed bytes of the header's own blocks
     std::string err;
 };
 
@@ -872,9 +873,16 @@ int ampbam_writer_open(const char *path, const char *header_text, int64_t header
         put32(t, (uint32_t)like->ref_lens[r]); okm = okm && append(b, t, 4);
     }
     if (!okm) { std::fclose(w->fp); delete w; return AMPBAM_ENOMEM; }
+    // the header gets BGZF blocks of its own (htslib flushes behind it too): the files that the ranks of a multi-GPU run write can
+    // then be joined block-wise, without the headers of the later ones (ampbam_writer_header_bytes)
+    const int rcf = flush_blocks(w, true);
+    if (rcf) { std::fclose(w->fp); delete w; return rcf; }
+    w->header_bytes = (int64_t)std::ftell(w->fp);
     *out = w;
     return AMPBAM_OK;
 }
+
+int64_t ampbam_writer_header_bytes(const ampbam_writer *w) { return w ? w->header_bytes : -1; }
 
 int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, const int64_t *src_index,
                       const uint8_t *keep, const int32_t *new_pos, const uint32_t *new_ncig,
@@ -922,6 +930,50 @@ int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, 
             std::memcpy(q + 32 + l_name, cg, 4ull * nn);
             const uint64_t tail_from = 32ull + l_name + 4ull * old_n;          // bases, qualities, aux
             std::memcpy(q + 32 + l_name + 4ull * nn, c + tail_from, bs - tail_from);
+        }
+    });
+    return flush_blocks(w, false);
+}
+
+int ampbam_write_batch(ampbam_writer *w, int64_t n, const int32_t *pos, const uint16_t *flag, const int32_t *tlen, const uint32_t *lseq,
+                       const uint64_t *cig_off, const uint32_t *cig, const uint64_t *seq_off, const uint8_t *seq, const uint8_t *qual,
+                       uint64_t name_base) {
+    if (!w || n < 0 || (n && (!pos || !flag || !tlen || !lseq || !cig_off || !cig || !seq_off || !seq || !qual))) return AMPBAM_EINVAL;
+    // sizes first (names are "r<number>"), so that rows can be encoded in parallel straight into the pending buffer
+    auto digits = [](uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t nc = cig_off[i + 1] - cig_off[i], L = lseq[i];
+        if (nc > 65535u || (seq_off[i] & 1)) return AMPBAM_EINVAL;
+        off[(size_t)i + 1] = off[(size_t)i] + 4 + 32 + (uint64_t)(2 + digits(name_base + (uint64_t)i)) + 4 * nc + (L + 1) / 2 + L;
+    }
+    const size_t base = w->pend.size();
+    if (!w->pend.resize(base + (size_t)off[(size_t)n])) return AMPBAM_ENOMEM;
+    uint8_t *ob = w->pend.data() + base;
+    const int64_t grain = 4096;
+    parallel_for(w->n_threads, (n + grain - 1) / grain, [&](int64_t ch) {
+        for (int64_t i = ch * grain; i < std::min(n, (ch + 1) * grain); ++i) {
+            uint8_t *o = ob + off[(size_t)i];
+            const uint32_t bs = (uint32_t)(off[(size_t)i + 1] - off[(size_t)i] - 4), nc = (uint32_t)(cig_off[i + 1] - cig_off[i]), L = lseq[i];
+            char name[24];
+            const int ln = std::snprintf(name, sizeof(name), "r%llu", (unsigned long long)(name_base + (uint64_t)i)) + 1;
+            const uint32_t *cg = cig + cig_off[i];
+            int64_t rlen = 0;
+            for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = cg[k] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cg[k] >> 4; }
+            const int64_t p = pos[i], end = p + (rlen ? rlen : 1);
+            put32(o, bs);
+            uint8_t *q = o + 4;
+            put32(q, 0); put32(q + 4, (uint32_t)pos[i]);
+            q[8] = (uint8_t)ln; q[9] = 60;
+            put16(q + 10, reg2bin(p > 0 ? p : 0, end > 1 ? end : 1));
+            put16(q + 12, (uint16_t)nc); put16(q + 14, flag[i]);
+            put32(q + 16, L); put32(q + 20, 0); put32(q + 24, (uint32_t)pos[i]); put32(q + 28, (uint32_t)tlen[i]);
+            std::memcpy(q + 32, name, (size_t)ln);
+            std::memcpy(q + 32 + ln, cg, 4ull * nc);
+            std::memcpy(q + 32 + ln + 4ull * nc, seq + seq_off[i] / 2, (L + 1) / 2);
+            if (L & 1) q[32 + ln + 4ull * nc + L / 2] &= 0xF0;                       // (the pad nibble of an odd read is zero)
+            std::memcpy(q + 32 + ln + 4ull * nc + (L + 1) / 2, qual + seq_off[i], L);
+            if (L && qual[seq_off[i]] == 0xFF) std::memset(q + 32 + ln + 4ull * nc + (L + 1) / 2, 0xFF, L);      // QUAL '*'
         }
     });
     return flush_blocks(w, false);

@@ -105,6 +105,13 @@ def gather_relevant_events(dist, rank, world, pairs, dst=0):
     return [p for part in gathered for p in part] if rank == dst else []
 
 
+def gather_objects(dist, rank, world, obj, dst=0):
+    """[obj of rank 0, obj of rank 1, ...] on ``dst`` (None on the other ranks)."""
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(obj, gathered, dst=dst)
+    return gathered
+
+
 def agree_on_positions(dist, rank, positions, src=0):
     """Broadcast the list of insertion-relevant positions decided on ``src``."""
     box = [positions if rank == src else None]

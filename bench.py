@@ -115,8 +115,18 @@ def main():
     t_gen = time.time() - t_gen
 
     mn, mx, mpl = lib.find_overlapping_primers(G, [(s, e) for s, e, _ in primers], 0)
-    rd = batch.struct()
     cp = calling.call_params(10, 0.0, 1, 0.03, True, True)
+    # Every step in flight works on a batch of ITS OWN (same generator, another seed: 8 x 0.5 GB in HBM), so that passes that run
+    # side by side do not stream the same half gigabyte through the 256 MB Infinity Cache.  (--strong: ONE job, every slot holds
+    # the rank's slice of it.)
+    slot_batches = {}
+
+    def batch_for(lane):
+        if args.strong or lane == 0:
+            return batch
+        if lane not in slot_batches:
+            slot_batches[lane] = synth_torch.make_amplicon_batch_device(genome, amps[a_lo:a_hi], job_reads, seed=1000 + rank + 7919 * lane, device=dev)
+        return slot_batches[lane]
 
     # The steps in flight are dealt over a few HIP streams (each step has its own engine, table and outputs).  The scan pass is
     # one block per CU for its whole duration, so on ONE stream the chip idles through every pass's last tile and through the
@@ -138,7 +148,9 @@ def main():
     class Slot:
         """One in-flight step: its own engine (device table, event list, scratch, pinned result image) and outputs."""
 
-        def __init__(self, b=batch, lane=0):
+        def __init__(self, b=None, lane=0):
+            b = batch_for(lane) if b is None else b
+            self.batch = b
             self.stream = work_streams[lane % len(work_streams)]
             self.eng = eng = lib.Engine(G, device=local_rank)
             eng.set_kernel_variant(args.variant)
@@ -196,7 +208,7 @@ def main():
         sl = slots[k % depth]
         with torch.cuda.stream(sl.stream):
             sl.eng.reset()
-            sl.eng.process_device(rd, 0, sl.dev_out)
+            sl.eng.process_device(sl.rd, 0, sl.dev_out)
             if comm_stream is None:
                 if dist is not None:
                     # ONE collective per step: afterwards every rank holds the whole job's table and makes the same calls
@@ -256,6 +268,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng, table, out_t = last["slot"].eng, last["slot"].table, last["slot"].out
+    batch = last["slot"].batch           # (the checks and the byte counts below are those of the LAST step's own batch)
+    rd = last["slot"].rd
     # outside the timed region: the same launches with nothing else on the GPU (the pipelined steps above
     # overlap them with the previous step's small kernels and with the next scan, which stretches their
     # own duration while shortening the step)
@@ -277,6 +291,25 @@ def main():
             parallel.allreduce_table(dist, table)
         torch.cuda.synchronize()
 
+    # ---- the box's own stream ceiling (report against the spec peak AND a measured copy): 1 GiB copied device to device,
+    # bytes read + bytes written over the HIP-event time of the copies
+    peak_measured = None
+    try:
+        src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        dst_t = torch.empty_like(src_t)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            dst_t.copy_(src_t)
+        ev0.record()
+        for _ in range(10):
+            dst_t.copy_(src_t)
+        ev1.record()
+        torch.cuda.synchronize()
+        peak_measured = 2.0 * src_t.numel() * 4 * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        del src_t, dst_t
+        torch.cuda.empty_cache()
+    except Exception:
+        peak_measured = None
     # ---- accounting (outside the timed region) ------------------------------------------------
     n_out = int(out_t["new_ncig"].sum().item())
     n_err = int((out_t["status"] != 0).sum().item())
@@ -451,7 +484,8 @@ def main():
             "value": round(total_reads / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": "synthetic 29,903 nt genome, 98-amplicon ARTIC-style primers, 150 bp paired reads, "
+            "config": {"batches": ("one batch per step in flight (%d distinct batches of the same generator, other seeds)" % (1 + len(slot_batches))) if not args.strong else "the rank's slice of the one job, shared by the steps in flight",
+                       "workload": "synthetic 29,903 nt genome, 98-amplicon ARTIC-style primers, 150 bp paired reads, "
                                    + ("ONE job of %d x depth = %d reads cut into %d coordinate slices of equal base counts" % (args.depth, job_reads, world)
                                       if args.strong else "%d x depth = %d reads per GPU" % (args.depth, n_reads))
                                    + ", inputs resident in HBM",
@@ -464,6 +498,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": SCAN_KERNELS.get(args.variant, "?"),
                          "achieved": round(alg_bytes / (k_rate_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg_bytes / (k_rate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "peak_measured": round(peak_measured, 1) if peak_measured else None,
+                         "frac_of_measured": round(alg_bytes / (k_rate_ms * 1e-3) / 1e9 / peak_measured, 5) if peak_measured else None,
+                         "frac_alone_of_measured": round(alg_bytes / k_solo / 1e6 / peak_measured, 5) if peak_measured else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_rate_ms, 5),
                          "kernel_ms_event_span": round(k_ms, 5),
                          "kernel_ms_alone": round(k_solo, 5),
@@ -480,7 +517,10 @@ def main():
                                  + ("kernel_ms_alone / frac_alone: the pass with the GPU to itself and its grid sized for all CUs (5 passes after "
                                     "the timed region, HIP events on the engine's stream; profiles/ hold the rocprofv3 kernel trace of this "
                                     "leg); inside the region a pass is sized for 1/%d of the CUs (amp_set_cu_share) and passes run side by side; "
-                                    "fast_kernel_ms_alone: the first kernel of the pass alone (k_fast for variant 4)" % cu_share)},
+                                    "fast_kernel_ms_alone: the first kernel of the pass alone (k_fast for variant 4). " % cu_share)
+                                 + "peak_measured: a 1 GiB device-to-device copy on this box (read + written bytes per second), frac_of_measured / "
+                                   "frac_alone_of_measured: the same two fractions against it.  traffic: HBM bytes per launch from the rocprofv3 "
+                                   "counter passes committed under profiles/ (a constant of the profile, not measured in this run: counters need the profiler)"},
             "cpu_baseline": cpu,
             "e2e": e2e,
             "extra": extra,

@@ -117,6 +117,18 @@ int ampbam_writer_open(const char *path, const char *header_text, int64_t header
 int ampbam_write_rows(ampbam_writer *w, const ampbam_file *src, int64_t n_rows, const int64_t *src_index,
                       const uint8_t *keep, const int32_t *new_pos, const uint32_t *new_ncig,
                       const uint64_t *new_cig_off, const uint32_t *new_cig);
+/* The new file starts with BGZF blocks that hold the header and nothing else: their size in the file.  The files written by the
+ * ranks of a multi-GPU run are joined into the ONE file AmpliPy.py writes (A:326-356, A:911) by copying part 0 without its
+ * EOF block and the later parts without their header blocks and EOF blocks, and ending with one EOF block (BGZF members
+ * concatenate). */
+int64_t ampbam_writer_header_bytes(const ampbam_writer *w);
+/* Appends the rows of a packed batch (the SoA of ampbam_decode / include/amplihip.h: 4-bit bases, one quality byte per base,
+ * BAM CIGAR words) as NEW records: name "r<name_base + row>", reference 0, MAPQ 60, mate on the read's own position, no aux
+ * fields.  For files made from synthetic or re-packed reads (the benchmarks' input files; tests); AmpliPy itself only ever
+ * re-writes records it has read (ampbam_write_rows, A:911).  seq_off in bases (even), as in the batch. */
+int ampbam_write_batch(ampbam_writer *w, int64_t n, const int32_t *pos, const uint16_t *flag, const int32_t *tlen, const uint32_t *lseq,
+                       const uint64_t *cig_off, const uint32_t *cig, const uint64_t *seq_off, const uint8_t *seq, const uint8_t *qual,
+                       uint64_t name_base);
 /* Flushes, writes the BGZF end-of-file block, closes the file and frees the writer. */
 int ampbam_writer_close(ampbam_writer *w);
 

@@ -392,3 +392,97 @@ def test_piece_walk_does_not_guess_record_starts(tmp_path, monkeypatch):
             total += f.n_records
             f.close()
         assert total == 500, n_parts
+
+
+def test_write_batch_round_trip(tmp_path):
+    """ampbam_write_batch (files made from packed rows: the benchmarks' inputs): odd and even read lengths, indel CIGARs, a read
+    without qualities; libampbam's own reader and the Python codec read back what was packed."""
+    from tools.e2e_legs import write_bam
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    segs = synth.make_mixed_segments(g, amps, 3000, seed=21)
+    segs[5].query_qualities = None
+    hb = ReadBatch.from_segments(segs)
+    seed = str(tmp_path / "seed.bam")
+    write_bam(seed, synth.make_amplicon_batch(g, amps, 8, seed=1), int(g.size))
+    like = bam_native.BamFile(seed)
+    out = str(tmp_path / "o.bam")
+    w = bam_native.BamWriter(out, like.header_text, like, level=1)
+    w.write_batch(hb, name_base=1000)
+    w.close(); like.close()
+    f = bam_native.BamFile(out)
+    assert f.n_records == hb.n
+    b, skipped = f.decode(0, f.n_records, copy=True)
+    assert skipped == 0
+    for name in ("pos", "flag", "tlen", "lseq", "cig_off", "cig", "seq_off", "seq", "qual"):
+        assert np.array_equal(getattr(b, name), getattr(hb, name)), name
+    f.close()
+    recs = list(bamio.AlignmentReader(out, "rb"))
+    assert len(recs) == hb.n and recs[0].qname == "r1000" and recs[5].qual is None
+    assert recs[7].seq == segs[7].query_sequence and recs[7].cigar == [tuple(t) for t in segs[7].cigartuples]
+
+
+def test_rank_files_join_into_one_bam_and_shares_balance(tmp_path, monkeypatch):
+    """A multi-rank run writes ONE trimmed BAM like AmpliPy.py does (A:326-356, A:911): every rank re-encodes the rows of its
+    share into a file of its own, rank 0 joins them block-wise (stitch_bam_parts: part 0 without its EOF block, the others
+    without header blocks and EOF block).  For 2, 3 and 8 ranks the joined file inflates to the same bytes as the file one
+    writer makes of all rows, ends with one EOF block and reads back record by record.  And the cut by compressed bytes
+    (native_parts / ampbam_open_range) gives ranks equal work on input of the config-5 kind (mixed 75-300 bp reads, soft clips,
+    indel-heavy CIGARs): bases per rank within 10 % of the mean."""
+    import gzip as gz
+    from amplipy_amd import amplipy
+    from tools.e2e_legs import write_bam
+    g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
+    hb = synth.make_config5_batch(g, amps, rep=6, pool_reads=20000)            # 120,000 reads of the config-5 mix
+    seed = str(tmp_path / "seed.bam")
+    write_bam(seed, synth.make_amplicon_batch(g, amps, 8, seed=1), int(g.size))
+    like = bam_native.BamFile(seed)
+    inp = str(tmp_path / "in.bam")
+    w = bam_native.BamWriter(inp, like.header_text, like, level=6)
+    w.write_batch(hb)
+    w.close()
+    rng = np.random.default_rng(8)
+
+    def rows_of(piece, writer):
+        b, _ = piece.decode(0, piece.n_records, copy=True)
+        keep = (b.pos % 7 != 0).astype(np.uint8)                                 # some rows dropped, like the write filter does
+        writer.write_rows(piece, b.src_index, keep, b.pos + 1, np.diff(b.cig_off.astype(np.int64)).astype(np.uint32), b.cig_off[:-1], b.cig)
+        return int(b.lseq.sum(dtype=np.int64))
+
+    monkeypatch.setenv("AMPLIPY_PART_BYTES", "400000")
+    whole = str(tmp_path / "whole.bam")
+    src = amplipy.NativeInput(inp, 0, 1)
+    first = src.first_part()
+    hdr_text = first.header_text
+    w = bam_native.BamWriter(whole, hdr_text, first, level=1)
+    for piece in src:
+        rows_of(piece, w); piece.close()
+    w.close()
+    want = gz.decompress(open(whole, "rb").read())
+    for world in (2, 3, 8):
+        parts, bases = [], []
+        for rank in range(world):
+            src = amplipy.NativeInput(inp, rank, world)
+            first = src.first_part()
+            path = str(tmp_path / ("w%d.part%d.bam" % (world, rank)))
+            w = bam_native.BamWriter(path, hdr_text, first, level=1)
+            nb = 0
+            for piece in src:
+                nb += rows_of(piece, w); piece.close()
+            w.close()
+            parts.append((path, w.header_bytes)); bases.append(nb)
+        out = str(tmp_path / ("joined%d.bam" % world))
+        bam_native.stitch_bam_parts(out, parts)
+        blob = open(out, "rb").read()
+        assert blob.endswith(bam_native.BGZF_EOF) and blob.count(bam_native.BGZF_EOF) >= 1
+        assert gz.decompress(blob) == want, world
+        f = bam_native.BamFile(out)
+        assert f.n_records == len(bamio_records(whole))
+        f.close()
+        mean = sum(bases) / world
+        assert sum(bases) == int(hb.lseq.sum(dtype=np.int64))
+        assert max(abs(b - mean) for b in bases) <= 0.10 * mean, (world, bases)
+    like.close()
+
+
+def bamio_records(path):
+    return list(bamio.AlignmentReader(path, "rb"))

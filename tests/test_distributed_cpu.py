@@ -152,10 +152,13 @@ def _worker_file_partition(rank, world, port, bam_path, out_dir, fail_rank):
         from amplipy_amd import amplipy, calling
         g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
         mn, mx, mpl = oracle.find_overlapping_primers(g.size, [(s, e) for s, e, _ in primers], 0)
+        from amplipy_amd import bam_native
         src = amplipy.NativeInput(bam_path, rank, world)
+        first = src.first_part()
+        wr = bam_native.BamWriter(os.path.join(out_dir, "trim.part%d.bam" % rank), first.header_text, first, level=1)
         table = np.zeros(g.size * 7, np.int64)
         runs = Counter()
-        n_rows = n_pieces = 0
+        n_rows = n_pieces = n_bases = 0
         err = None
         try:
             for piece in src:
@@ -163,6 +166,11 @@ def _worker_file_partition(rank, world, port, bam_path, out_dir, fail_rank):
                 if piece.n_records:
                     b, _ = piece.decode(0, piece.n_records, copy=True)
                     r = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+                    # the rank's trimmed reads, with the write filter of AmpliPy.py:910, into the rank's own file
+                    keep = (r.trim.ref_len >= 30) & ((r.trim.trim_flags & 3) != 0)
+                    slot = b.cig_off[:-1] + np.uint64(3) * np.arange(b.n, dtype=np.uint64)
+                    wr.write_rows(piece, b.src_index, keep, r.trim.new_pos, r.trim.new_ncig, slot, r.trim.new_cig)
+                    n_bases += int(b.lseq.sum(dtype=np.int64))
                     table[:g.size * 6] += r.counts.reshape(-1)
                     np.add.at(table[g.size * 6:], r.events["ref_pos"], 1)
                     runs.update(event_strings(b, r.events))
@@ -172,11 +180,19 @@ def _worker_file_partition(rank, world, port, bam_path, out_dir, fail_rank):
                 raise ValueError("made-up failure of one rank")
         except Exception as e:
             err = e
+        wr.close()
         trouble = parallel.exchange_notes(dist, world, getattr(src, "seam", [None, None]), err)
         if trouble:
             with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
                 f.write(trouble)
             return
+        # ONE trimmed BAM, like the single-process run writes: rank 0 joins the ranks' files (run_amplipy does exactly this)
+        parts = parallel.gather_objects(dist, rank, world, (wr.path, wr.header_bytes))
+        shares = parallel.gather_objects(dist, rank, world, (n_rows, n_bases))
+        if rank == 0:
+            bam_native.stitch_bam_parts(os.path.join(out_dir, "trim.bam"), parts)
+            with open(os.path.join(out_dir, "shares.txt"), "w") as f:
+                f.write(repr(shares))
         t = torch.from_numpy(table.astype(np.int32))
         parallel.allreduce_table(dist, t)
         rel = set(int(p) for p in np.nonzero(t.numpy()[g.size * 6:])[0][::53])        # same on every rank by construction
@@ -214,6 +230,19 @@ def test_run_amplipys_file_partition_and_gather(tmp_path, world):
         assert int(got["n_pieces"]) >= 2               # the share really was walked piece by piece
         rows += int(got["n_rows"])
     assert rows == batch.n                             # every record belongs to exactly one rank
+    # the joined trimmed BAM of the ranks inflates to the bytes one writer makes of the whole file
+    import gzip as gz
+    whole = bam_native.BamFile(bam)
+    wb, _ = whole.decode(0, whole.n_records, copy=True)
+    keep = (ref.trim.ref_len >= 30) & ((ref.trim.trim_flags & 3) != 0)
+    one = str(tmp_path / "one.bam")
+    w1 = bam_native.BamWriter(one, whole.header_text, whole, level=1)
+    w1.write_rows(None, wb.src_index, keep, ref.trim.new_pos, ref.trim.new_ncig, wb.cig_off[:-1] + np.uint64(3) * np.arange(wb.n, dtype=np.uint64), ref.trim.new_cig)
+    w1.close(); whole.close()
+    joined = open(str(out / "trim.bam"), "rb").read()
+    assert joined.endswith(bam_native.BGZF_EOF) and gz.decompress(joined) == gz.decompress(open(one, "rb").read())
+    shares = eval((out / "shares.txt").read_text())
+    assert sum(r_ for r_, _ in shares) == batch.n and sum(b_ for _, b_ in shares) == int(batch.lseq.sum())
     # one rank fails in front of the collective: every rank learns of it instead of waiting in the all-reduce
     bad = tmp_path / "bad"; bad.mkdir()
     mp.spawn(_worker_file_partition, args=(world, _free_port(), bam, str(bad), world - 1), nprocs=world, join=True)

@@ -871,6 +871,19 @@ def test_single_rank_rccl_paths(tmp_path, scheme, monkeypatch):
         outs[tag] = ([l for l in open(v) if not l.startswith("##")], open(c).read())
     assert outs["plain"] == outs["dist"]
     assert len(outs["plain"][0]) > 1
+    # (d) the benchmark's multi-rank path with one rank: the all-reduce on a stream of its own under the next step's reads, the
+    # strong-scaling slice of ONE job and its bit-identity check (what `--gpus 8 --strong` runs, minus the other seven ranks)
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29545", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", AMPLIPY_FORCE_DIST="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--strong", "--depth", "1000", "--steps", "6",
+                          "--warmup", "2", "--cpu-passes", "-1", "--no-e2e", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["config"]["rccl_ranks"] == 1 and line["config"]["collective_on_own_stream"]
+    assert line["config"]["strong_check"] and line["config"]["error_reads"] == 0
 
 
 def test_amp_reduce_with_a_real_rccl_communicator(scheme):
