@@ -175,6 +175,19 @@ class NativeInput:
         t.start()
         self._ahead = (t, box)
 
+    def close(self):
+        """Lets go of what an abandoned walk still holds: the piece that was being opened ahead, the first piece if it was never
+        yielded."""
+        if self._ahead is not None:
+            t, box = self._ahead
+            t.join()
+            if box.get("file") is not None:
+                box["file"].close()
+            self._ahead = None
+        if self._first is not None:
+            self._first.close()
+            self._first = None
+
     def __iter__(self):
         """Yields the pieces in order; the caller closes each when it is done with it.  seam = (first, end) of the whole
         share is available afterwards."""
@@ -200,6 +213,7 @@ class NativeInput:
             if k + 1 < self.k_hi:
                 t, box = self._ahead
                 t.join()
+                self._ahead = None
                 if "error" in box:
                     raise box["error"]
                 cur = box["file"]
@@ -340,28 +354,35 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         print_log("Precalculating overlapping primers...")
         mn, mx, mpl = lib.find_overlapping_primers(G, primers, primer_pos_offset)
         eng.set_primers(mn, mx, mpl)
-    native = None
-    if run_trim:
-        print_log("Input untrimmed SAM/BAM: %s" % untrimmed_reads_fn)
-        print_log("Output trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        native = open_native_bam(untrimmed_reads_fn, trimmed_reads_fn, rank, world)
-        if native is None:
-            reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
-    else:
-        print_log("Input trimmed SAM/BAM: %s" % trimmed_reads_fn)
-        native = open_native_bam(trimmed_reads_fn, None, rank, world)
-        if native is None:
-            reader, writer = open_alignment_files(trimmed_reads_fn, None)
-    vcf = None
-    if variants_fn is not None and rank == 0:
-        print_log("Output variants VCF: %s" % variants_fn)
-        vcf = VcfWriter(variants_fn, ref_id)
+    # Opening the files can fail on ONE rank of a multi-rank run (a missing share, an output that exists): the other ranks must
+    # not be left waiting in the collective, so with several ranks the failure is carried to the exchange in front of it
+    native = reader = writer = vcf = None
+    rank_error = None
+    try:
+        if run_trim:
+            print_log("Input untrimmed SAM/BAM: %s" % untrimmed_reads_fn)
+            print_log("Output trimmed SAM/BAM: %s" % trimmed_reads_fn)
+            native = open_native_bam(untrimmed_reads_fn, trimmed_reads_fn, rank, world)
+            if native is None:
+                reader, writer = open_alignment_files(untrimmed_reads_fn, trimmed_reads_fn)
+        else:
+            print_log("Input trimmed SAM/BAM: %s" % trimmed_reads_fn)
+            native = open_native_bam(trimmed_reads_fn, None, rank, world)
+            if native is None:
+                reader, writer = open_alignment_files(trimmed_reads_fn, None)
+        if variants_fn is not None and rank == 0:
+            print_log("Output variants VCF: %s" % variants_fn)
+            vcf = VcfWriter(variants_fn, ref_id)
+    except (Exception, SystemExit) as e:
+        if dist is None:
+            raise
+        rank_error = e if isinstance(e, Exception) else RuntimeError("could not open the run's files (exit status %s)" % (e.code,))
+        native = None
     do_count = run_variants or run_consensus
     eng.set_params(min_quality if min_quality is not None else 20,
                    sliding_window_width if sliding_window_width is not None else 4, run_trim, do_count)
 
     print_log("Processing reads...")
-    rank_error = None
     writer_pending = False      # the writer thread of the native BAM path is still running (joined behind the calls)
     ins_store = EventStore()             # insertion events with their allele text (each batch's bases are at hand only now)
     pending = []
@@ -392,7 +413,10 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
 
     n_seen = 0                           # records this rank has gone through (all of them when there is one rank)
     n_bases = 0                          # ... and their bases (the measure the shares of a multi-rank run should be equal in: SURVEY 8e)
-    if native is not None:
+    seam = [None, None]
+    if rank_error is not None:
+        pass                              # (nothing was opened: straight to the exchange)
+    elif native is not None:
         # BAM in (and BAM or nothing out): libampbam decodes records straight into packed batches and
         # re-encodes the kept ones; no per-read Python object exists on this path.  The file is walked piece by piece:
         # piece k + 1 is inflated and indexed on a helper thread while piece k is decoded, trimmed and counted, and a
@@ -458,6 +482,8 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
                 raise
             rank_error = e
         finally:
+            if not loop_done:
+                src.close()                 # (the piece opened ahead of the one that failed)
             if wq is not None:
                 wq.put(None)
                 # One process: the writer thread goes on re-encoding and deflating the last rows under the calls and the VCF
@@ -554,6 +580,11 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
     finally:
         if writer_pending:
             wthread.join()
+            if nwriter is not None and sys.exc_info()[0] is not None:
+                try:                        # (the calls failed: the trimmed BAM is still ended properly)
+                    nwriter.close()
+                except Exception:
+                    pass
     if writer_pending:
         if werr:
             raise werr[0]

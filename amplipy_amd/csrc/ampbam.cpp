@@ -613,10 +613,27 @@ int ampbam_open_range_at(const char *path, int n_threads, int part, int n_parts,
     MappedFile raw;
     int rc = raw.map(path);
     if (rc) return rc;
+    // The BGZF block table is the same for every piece of a file: a process that walks a file piece by piece hops over the
+    // block headers of the whole file ONCE (keyed by path, size and modification time), not once per piece -- on a 10 GB file
+    // that was two minutes of page faults over 2,500 pieces
     std::vector<Block> blocks;
     size_t total = 0;
-    rc = block_table(raw, blocks, total);
-    if (rc) return rc;
+    {
+        static std::mutex mu;
+        static std::string c_path; static size_t c_size = 0; static int64_t c_mtime = 0; static size_t c_total = 0;
+        static std::vector<Block> c_blocks;
+        struct stat st;
+        const bool have_st = ::stat(path, &st) == 0;
+        const int64_t mt = have_st ? (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec : -1;
+        std::lock_guard<std::mutex> lk(mu);
+        if (have_st && c_path == path && c_size == raw.n && c_mtime == mt && !c_blocks.empty()) {
+            blocks = c_blocks; total = c_total;
+        } else {
+            rc = block_table(raw, blocks, total);
+            if (rc) return rc;
+            if (have_st && n_parts > 1) { c_path = path; c_size = raw.n; c_mtime = mt; c_blocks = blocks; c_total = total; }
+        }
+    }
     const int64_t nb = (int64_t)blocks.size();
     if (nb == 0) return AMPBAM_EFORMAT;
     ampbam_file *f = new (std::nothrow) ampbam_file();

@@ -14,7 +14,9 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AMPLIHIP_LIB") or os.path.join(_HERE, "libamplihip.so")      # (AMPLIHIP_LIB: another build of the same library, for A/B timing)
+# (development only -- AMPLIPY_DEV=1 AMPLIHIP_LIB=path: another build of the same library, for A/B timing by the tools under tools/;
+#  the shipped package loads the library that lies next to this file and nothing else)
+LIB_PATH = (os.environ.get("AMPLIHIP_LIB") if os.environ.get("AMPLIPY_DEV") == "1" else None) or os.path.join(_HERE, "libamplihip.so")
 _LIB = None
 
 EXPORTS = [
