@@ -1043,7 +1043,7 @@ k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
     F_STAMP_OUT;
-    if (tid == 0) gcnt[blockIdx.x] = s_gcur;
+    if (tid == 0) { gcnt[blockIdx.x] = s_gcur; if (s_gcur) eb.ctr[29] = (unsigned long long)P.epoch; }      // (every block writes the same value)
 }
 
 // Dense list of the reads the fast kernel handed over + the geometry of the general pass.  Block b places the

@@ -612,7 +612,7 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
         }
     }
     if (n_err) atomicAdd(&ctr[2], (unsigned long long)n_err);
-    if (tid == 0) gcnt[blockIdx.x] = s_gcur;
+    if (tid == 0) { gcnt[blockIdx.x] = s_gcur; if (s_gcur) eb.ctr[29] = (unsigned long long)P.epoch; }      // (every block writes the same value)
 }
 
 struct Fast5Cfg { int waves, qrun; };

@@ -177,6 +177,17 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t x) {
 
 // phase stamps of development builds (-DAMP_F6_STAMPS: cycles per phase summed over the waves into ctr[8 ..], turns into ctr[6]); the
 // shipped library has none
+#ifdef AMP_F6_WAITSTAMPS
+#define F6_WS_DECL unsigned long long f6_w[4] = {0, 0, 0, 0}, f6_wt = 0; unsigned long long f6_wn = 0
+#define F6_WS_BEGIN do { __builtin_amdgcn_s_waitcnt(0xC07F); f6_wt = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+#define F6_WS_END(k) do { const unsigned long long f6_n = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); f6_w[k] += f6_n - f6_wt; f6_wt = f6_n; } while (0)
+#define F6_WS_OUT do { if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&ctr[8 + k], f6_w[k]); atomicAdd(&ctr[6], f6_wn); } } while (0)
+#else
+#define F6_WS_DECL
+#define F6_WS_BEGIN
+#define F6_WS_END(k)
+#define F6_WS_OUT
+#endif
 #ifdef AMP_F6_STAMPS
 #define F6_STAMP_DECL unsigned long long f6_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f6_prev = __builtin_amdgcn_s_memtime(); unsigned long long f6_turns = 0
 #define F6_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long f6_n = __builtin_amdgcn_s_memtime(); f6_t[k] += f6_n - f6_prev; f6_prev = f6_n; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -206,7 +217,7 @@ struct F6Hdr {                 // a read's header as kept between tiles
 #define F6_PARAMS \
     const int32_t *a_pos, int32_t a_min_quality, const uint16_t *a_flag, int32_t a_window, const int32_t *a_tlen, int32_t a_do_trim, \
     const uint32_t *a_lseq, int32_t a_do_count, const uint32_t *a_cig_off32, int32_t a_ref_len, const uint32_t *a_cig, int32_t a_max_primer_len, \
-    const uint32_t *a_seq_off8, int32_t reads_per_block, const uint8_t *a_seq, int32_t pad0, const uint8_t *a_qual, int32_t pad1, \
+    const uint32_t *a_seq_off8, int32_t reads_per_block, const uint8_t *a_seq, int32_t a_epoch, const uint8_t *a_qual, int32_t pad1, \
     const int32_t *a_min_start, int32_t pad2, const int32_t *a_max_end, int32_t pad3, \
     int32_t *a_new_pos, int32_t pad4, uint32_t *a_new_ncig, int32_t pad5, uint32_t *a_new_cig, int32_t pad6, int32_t *a_o_ref_len, int32_t pad7, \
     uint8_t *a_trim_flags, int32_t pad8, uint8_t *a_status, int32_t pad9, \
@@ -217,7 +228,7 @@ struct F6Hdr {                 // a read's header as kept between tiles
 template <int W>
 __global__ void __launch_bounds__(F6_WAVES * 64, 2)
 k_fast6(F6_PARAMS) {
-    const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end};
+    const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end, (uint32_t)a_epoch};
     const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
     const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
     const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
@@ -500,6 +511,7 @@ k_fast6(F6_PARAMS) {
     }
 
     F6_STAMP_DECL;
+    F6_WS_DECL;
     auto turn = [&](auto itag) {
         constexpr bool ITILE = decltype(itag)::value;                   // a tile of indel reads
         F6_TURN; F6_STAMP(7);
@@ -656,7 +668,9 @@ k_fast6(F6_PARAMS) {
         bool want_status = false;
         bool slow_all = counted && (uint32_t)end_pos > G;
         F6_STAMP(3);          // clips, results
+        F6_WS_BEGIN;
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the header of the tile after the next, requested at the top of the turn
+        F6_WS_END(0);
         F6_STAMP(2);          // wait
         // ---- pass 1b: the codes of the low-quality bases become zero; the masked pieces go back piece-major -------------------
         uint4 iq16 = make_uint4(0u, 0u, 0u, 0u);
@@ -882,7 +896,11 @@ k_fast6(F6_PARAMS) {
         push_list(general || (stored && !ts.err && P.do_count && want_status),
                   (uint32_t)i | (general ? 0u : GL_STATUS_ONLY));          // (status only: a base could not be counted, exact status wanted)
         // ---- everything asked for behind pass 1b has arrived ----------------------------------------------------------------------
+#ifdef AMP_F6_WAITSTAMPS
+        { const unsigned long long f6_a = __builtin_amdgcn_s_memtime(); F6_WS_BEGIN; f6_w[2] += f6_wt - f6_a; ++f6_wn; }      // (the drain of the adds)
+#endif
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        F6_WS_END(1);
         tk0 = tk1; tk1 = tk2; tk2 = tk3;
         h0 = h1; h1 = h2; cw0 = c1w; e2 = e3; sr0 = sr1;
     };
@@ -907,7 +925,8 @@ k_fast6(F6_PARAMS) {
     }
     if (n_err) atomicAdd(&ctr[2], n_err);
     F6_STAMP_OUT;
-    if (tid == 0) gcnt[blockIdx.x] = s_gcur;
+    F6_WS_OUT;
+    if (tid == 0) { gcnt[blockIdx.x] = s_gcur; if (s_gcur) eb.ctr[29] = (unsigned long long)P.epoch; }      // (every block writes the same value)
 }
 
 static inline FastGrid fast6_grid(int64_t n_reads, int n_cu) {
@@ -922,7 +941,7 @@ static inline int fast6_launch(const KParams &P, const amp_dev_reads &rd, uint64
     const unsigned g = (unsigned)fg.grid, t = F6_WAVES * 64;
     const int rpb = (int)fg.rpb;
 #define F6_GO(w) k_fast6<w><<<g, t, 0, stream>>>(rd.pos, P.min_quality, rd.flag, P.window, rd.tlen, P.do_trim, rd.lseq, P.do_count, rd.cig_off32, P.ref_len, rd.cig, \
-        P.max_primer_len, rd.seq_off8, rpb, rd.seq, 0, rd.qual, 0, P.min_start, 0, P.max_end, 0, out.new_pos, 0, out.new_ncig, 0, out.new_cig, 0, out.ref_len, 0, \
+        P.max_primer_len, rd.seq_off8, rpb, rd.seq, (int32_t)P.epoch, rd.qual, 0, P.min_start, 0, P.max_end, 0, out.new_pos, 0, out.new_ncig, 0, out.new_cig, 0, out.ref_len, 0, \
         out.trim_flags, 0, out.status, 0, counts, 0, eb.ev, 0, eb.ctr, 0, eb.ins_at, 0, glist, 0, gcnt, 0, clist, 0, rd.n_reads, 0, read_base, 0, eb.cap)
     switch (P.window) {
         case 1: F6_GO(1); break;

@@ -31,6 +31,8 @@ struct KParams {
     int32_t min_quality, window, do_trim, do_count;
     int32_t ref_len, max_primer_len;
     const int32_t *min_start, *max_end;  // -1 = None; valid when do_trim
+    uint32_t epoch = 0;                  // number of the launch (a fast kernel that hands reads to the general pass leaves it in ctr[29]: the pass
+                                         // after a launch without such reads ends at its first instruction instead of adding up 256 list lengths)
 };
 
 // Device pointers of amp_trim_out (any may be null except new_cig, which the launcher always provides).

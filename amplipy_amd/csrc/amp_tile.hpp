@@ -591,6 +591,16 @@ k_tile(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *co
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool direct = LIST && ls.glist != nullptr;
     uint32_t n_list_direct = 0;
+    if (direct && (uint32_t)ctr[29] != P.epoch) {
+        // no block of this launch's fast kernel handed a read over: an empty pass (what the code below finds out after adding up the
+        // list lengths of all blocks; the batches of an amplicon run are like this nine times in ten)
+        if (blockIdx.x == 0 && tid == 0) {
+            ls.geo_out->n_list = 0u; ls.geo_out->tpb = (uint32_t)T_WAVES; ls.geo_out->n_seg = 0u; ls.geo_out->live_counted = 0u;
+            ctr[7] = 0ull;
+        }
+        if (tid == 0) { dcnt[blockIdx.x] = 0; dcnt[5 * dcnt_stride + 64 + blockIdx.x] = 0; }
+        return;
+    }
     if (direct) {
         if (tid <= GL_MAXSEG) L.gpre[tid] = tid < ls.n_gseg ? ls.gcnt[tid] : 0u;
         __syncthreads();

@@ -88,6 +88,7 @@ struct amp_ctx {
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
     int cu_share = 1;              // the fast kernels of this ctx are sized for n_cu / cu_share CUs (amp_set_cu_share)
+    uint32_t epoch = 0;            // launches of the read kernels so far (KParams::epoch)
     int kernel_variant = 0;       // 0 = by the batch (4 for reads of up to 152 padded bases on average, else 5), 5 = fast kernel (second generation) + general pass, 4 = its first generation, 1 = one lane per read (reference kernels), 2 = fused tile kernel, 3 = k_trim + k_scan + k_tile<SPLIT>,
                                   // 4 = k_fast (simple reads, one pass over their bytes) + k_tile<LIST> over the others
     uint32_t *dbg_dcnt = nullptr; int dbg_grid = 0;
@@ -1070,7 +1071,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         const int64_t need = (int64_t)(mx + 2 * h[1]) + fgb.grid * F_WAVES * (int64_t)F_EVGRAN + 2 * (int64_t)c->n_cu * L_WAVES * L_EVCAP;
         if (need > c->ev_cap) HIPCHK(c, grow_events(c, std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2)));
     }
-    KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end};
+    KParams P{c->min_quality, c->window, c->do_trim, c->do_count, c->ref_len, c->max_primer_len, c->d_min_start, c->d_max_end, ++c->epoch};
     if (n > 0x7FFFFFFFll) return AMP_EINVAL;
     const size_t slots = (size_t)rd->n_cig + 3 * (size_t)n;
     DevOut out{o ? o->new_pos : nullptr, o ? o->new_ncig : nullptr, o ? o->new_cig : nullptr, o ? o->ref_len : nullptr,

@@ -167,7 +167,11 @@ int amp_ctx_bind_counts(amp_ctx *ctx, void *dev_counts);
 int amp_set_primers(amp_ctx *ctx, const int32_t *min_primer_start,
                     const int32_t *max_primer_end, int32_t max_primer_len);
 /* min_quality / sliding_window_width of AmpliPy.py:907,915; do_trim = run_trim,
- * do_count = run_variants or run_consensus (AmpliPy.py:906, 914). */
+ * do_count = run_variants or run_consensus (AmpliPy.py:906, 914).
+ * Any window >= 1 and any min_quality >= 0 give the reference's results; the FAST kernels (closed-form trims, one lane per
+ * read) are built for windows of 1..8 bases and min_quality <= 128: a run outside of that takes the general tile kernel for
+ * every read (about 1.5 x the time per batch, same results).  The third-generation kernel (variant 6) additionally needs
+ * min_quality >= 1. */
 int amp_set_params(amp_ctx *ctx, int32_t min_quality, int32_t window, int32_t do_trim,
                    int32_t do_count);
 
@@ -248,7 +252,8 @@ int amp_reserve_events(amp_ctx *ctx, int64_t cap);
 /* 0 (default) = chosen per batch between 4 and 5 by its mean padded read length (up to 152: 4) and the window (8: 5).  4 = the fast kernel (closed-form trim +
  * pileup of reads with one match op or one insertion / deletion of up to 152 bases, every byte loaded once) followed by the
  * general pass over the reads it hands over; 5 = its second generation (reads consumed from LDS staging buffers,
- * branch-free closed forms, reads of up to 304 bases); 2 = the fused tile kernel over every read; 1 = one-lane-per-read
+ * branch-free closed forms, reads of up to 304 bases); 6 = its third generation (reads of up to 160 bases sorted into class
+ * lists per block, rows gathered by LDS-DMA, three passes from LDS: amp_fast6.hpp; opt-in); 2 = the fused tile kernel over every read; 1 = one-lane-per-read
  * kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks (all give
  * identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);

@@ -30,6 +30,9 @@ for it in range(a.iters):
     e.reset(); e.process_device(rd, 0, dev_out); e.sync(); ms.append(e.last_kernel_ms())
 print("variant %d window %d depth %d reads %d: total/scan ms per launch:" % (a.variant, a.window, a.depth, n), ["%.3f/%.3f" % m for m in ms])
 if not os.environ.get("AMP_STAMPS"): print("general-pass reads of the last launch:", int(e.debug_counters()[7]))
+if os.environ.get("AMP_F6_WAITSTAMPS"):
+    dc = e.debug_counters(); turns = max(int(dc[6]), 1)
+    print("k_fast6 waits (last launch): turns %d; cycles per turn: wait in front of pass 1b %.0f, wait at the end of the turn %.0f, drain of the adds in front of it %.0f" % (turns, int(dc[8]) / turns, int(dc[9]) / turns, int(dc[10]) / turns))
 if os.environ.get("AMP_F6_STAMPS"):
     dc = e.debug_counters(); turns = max(int(dc[6]), 1)
     names = ["requests+anchor", "pass 1a", "wait", "clips+results", "pass 1b", "requests+range ends", "pass 2", "tail+end wait"]
