@@ -287,10 +287,24 @@ __device__ __forceinline__ uint32_t count_piece5(const uint2 &sq, uint32_t m16, 
     const uint32_t so1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.y & 0x07070707u);
     const uint32_t f0 = nibble_to_bytes(m, 0), f1 = nibble_to_bytes(m, 1), f2 = nibble_to_bytes(m, 2), f3 = nibble_to_bytes(m, 3);
     const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u : 0u);
-    add_base2<0, 0, 0>(wb, se0, f0);   add_base2<0, 1, 1>(wb, so0, f0);   add_base2<1, 2, 2>(wb, se0, f0);   add_base2<1, 3, 3>(wb, so0, f0);
-    add_base2<2, 0, 4>(wb, se0, f1);   add_base2<2, 1, 5>(wb, so0, f1);   add_base2<3, 2, 6>(wb, se0, f1);   add_base2<3, 3, 7>(wb, so0, f1);
-    add_base2<0, 0, 8>(wb, se1, f2);   add_base2<0, 1, 9>(wb, so1, f2);   add_base2<1, 2, 10>(wb, se1, f2);  add_base2<1, 3, 11>(wb, so1, f2);
-    add_base2<2, 0, 12>(wb, se1, f3);  add_base2<2, 1, 13>(wb, so1, f3);  add_base2<3, 2, 14>(wb, se1, f3);  add_base2<3, 3, 15>(wb, so1, f3);
+    // the 16 shift + add pairs of the piece in ONE asm statement (round 4: between separate statements the compiler puts hazard
+    // s_nops it cannot rule out -- ~100 issue slots per tile); two temporaries alternate, a shift is issued while the add before it
+    // is on its way.  Base b of the piece: shift count = byte (b >> 1) & 3 of the even / odd shift word of its half, value = byte
+    // b & 3 of the flag word of its group of four
+#define F_SH(d, sh, js, v, jv) "v_lshlrev_b32_sdwa " d ", " sh ", " v " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #js " src1_sel:BYTE_" #jv "\n\t"
+#define F_AD(t, off) "ds_add_u32 %2, " t " offset:" #off "\n\t"
+    {
+        uint32_t t0, t1;
+        asm volatile(F_SH("%0", "%3", 0, "%7", 0) F_SH("%1", "%4", 0, "%7", 1) F_AD("%0", 0) F_SH("%0", "%3", 1, "%7", 2) F_AD("%1", 4) F_SH("%1", "%4", 1, "%7", 3)
+                     F_AD("%0", 8) F_SH("%0", "%3", 2, "%8", 0) F_AD("%1", 12) F_SH("%1", "%4", 2, "%8", 1) F_AD("%0", 16) F_SH("%0", "%3", 3, "%8", 2)
+                     F_AD("%1", 20) F_SH("%1", "%4", 3, "%8", 3) F_AD("%0", 24) F_SH("%0", "%5", 0, "%9", 0) F_AD("%1", 28) F_SH("%1", "%6", 0, "%9", 1)
+                     F_AD("%0", 32) F_SH("%0", "%5", 1, "%9", 2) F_AD("%1", 36) F_SH("%1", "%6", 1, "%9", 3) F_AD("%0", 40) F_SH("%0", "%5", 2, "%10", 0)
+                     F_AD("%1", 44) F_SH("%1", "%6", 2, "%10", 1) F_AD("%0", 48) F_SH("%0", "%5", 3, "%10", 2) F_AD("%1", 52) F_SH("%1", "%6", 3, "%10", 3)
+                     F_AD("%0", 56) "ds_add_u32 %2, %1 offset:60"
+                     : "=&v"(t0), "=&v"(t1) : "v"(wb), "v"(se0), "v"(so0), "v"(se1), "v"(so1), "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "memory");
+    }
+#undef F_SH
+#undef F_AD
     return redo ? 1u : 0u;
 }
 // bits [klo, khi) of a 16-bit mask, klo / khi clamped to 0..16
@@ -326,10 +340,32 @@ __device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
 #define F_STAMP_OUT
 #endif
 
+// The kernel's arguments are passed one by one, every pointer followed by a 32-bit value (round 4): a struct argument -- and a run of
+// adjacent pointers -- is loaded as ONE wide register tuple, and a kernel as short of scalar registers as this one spills and
+// reloads the whole tuple around every use of one field.
+#define F_ARGS \
+    const int32_t *a_pos, int32_t a_min_quality, const uint16_t *a_flag, int32_t a_window, const int32_t *a_tlen, int32_t a_do_trim, \
+    const uint32_t *a_lseq, int32_t a_do_count, const uint32_t *a_cig_off32, int32_t a_ref_len, const uint32_t *a_cig, int32_t a_max_primer_len, \
+    const uint32_t *a_seq_off8, int32_t reads_per_block, const uint8_t *a_seq, int32_t a_epoch, const uint8_t *a_qual, int32_t pad1, \
+    const int32_t *a_min_start, int32_t pad2, const int32_t *a_max_end, int32_t pad3, \
+    int32_t *a_new_pos, int32_t pad4, uint32_t *a_new_ncig, int32_t pad5, uint32_t *a_new_cig, int32_t pad6, int32_t *a_o_ref_len, int32_t pad7, \
+    uint8_t *a_trim_flags, int32_t pad8, uint8_t *a_status, int32_t pad9, \
+    uint32_t *counts, int32_t pad10, amp_ins_event *a_ev, int32_t pad11, unsigned long long *a_ctr, int32_t pad12, uint32_t *a_ins_at, int32_t pad13, \
+    uint32_t *glist, int32_t pad14, uint32_t *gcnt, int32_t pad15, \
+    int64_t a_n_reads, int32_t pad17, uint64_t read_base, int32_t pad18, long long a_ev_cap
+#define F_ARGS_PASS(P, rd, out, eb, rpb) \
+    (rd).pos, (P).min_quality, (rd).flag, (P).window, (rd).tlen, (P).do_trim, (rd).lseq, (P).do_count, (rd).cig_off32, (P).ref_len, (rd).cig, \
+    (P).max_primer_len, (rd).seq_off8, (rpb), (rd).seq, (int32_t)(P).epoch, (rd).qual, 0, (P).min_start, 0, (P).max_end, 0, (out).new_pos, 0, (out).new_ncig, 0, \
+    (out).new_cig, 0, (out).ref_len, 0, (out).trim_flags, 0, (out).status, 0, counts, 0, (eb).ev, 0, (eb).ctr, 0, (eb).ins_at, 0, glist, 0, gcnt, 0, \
+    (rd).n_reads, 0, read_base, 0, (eb).cap
+
 template <int W>
 __global__ void __launch_bounds__(F_WAVES * 64, 2)
-k_fast(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
-       int reads_per_block F_DBG_PARAM) {
+k_fast(F_ARGS F_DBG_PARAM) {
+    const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end, (uint32_t)a_epoch};
+    const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
+    const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
+    const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     // THREE separate LDS objects, not one struct: the compiler orders every LDS access behind LDS-DMA loads in flight
     // (s_waitcnt vmcnt) unless alias scopes tell it that the access cannot touch the DMA's destination, and it only
     // builds those scopes per LDS variable.  With one struct every counter add waited for the next tile's bytes.
@@ -1126,14 +1162,14 @@ static inline int fast_launch(const KParams &P, const amp_dev_reads &rd, uint64_
     const unsigned g = (unsigned)fg.grid, t = F_WAVES * 64;
     const int rpb = (int)fg.rpb;
     switch (P.window) {
-        case 1: k_fast<1><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 2: k_fast<2><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 3: k_fast<3><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 4: k_fast<4><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 5: k_fast<5><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 6: k_fast<6><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        case 7: k_fast<7><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
-        default: k_fast<8><<<g, t, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb F_DBG_ARG(dbg)); break;
+        case 1: k_fast<1><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 2: k_fast<2><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 3: k_fast<3><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 4: k_fast<4><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 5: k_fast<5><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 6: k_fast<6><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        case 7: k_fast<7><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
+        default: k_fast<8><<<g, t, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb) F_DBG_ARG(dbg)); break;
     }
     return (int)hipGetLastError();
 }

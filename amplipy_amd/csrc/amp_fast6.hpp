@@ -1,8 +1,12 @@
 // amp_fast6.hpp -- the fast kernel, third generation (variant 6): trim + pileup of the reads whose CIGAR has the shape
 // [S a][M m1]([I|D k][M m2])[S c] and at most 160 bases, one lane per read, every byte of the batch loaded once.  CDNA4 / gfx950.
 //
-// What the counters of the first two generations showed (profiles/r03_*, tools/micro/valu_rate3.hip): the kernel is bound by
-// the vector pipe of a SIMD, and not every instruction costs the same there -- add / sub / shift / and / or / compare /
+// Written to test two readings of what bounds the first two generations: "a tile pays the trims of a read
+// with an indel for 64 reads of which six have one" and "fewer, cheaper instructions make the pass faster".  Outcome: 23 % fewer
+// vector instructions than amp_fast.hpp and the same time -- row traffic, the vector pipe and the LDS round trips each need a
+// third of the kernel's time and overlap only partly at two waves per SIMD.  The kernel is therefore an opt-in variant
+// (amp_set_kernel_variant(6)); it gives the same results as the others (tests/test_gpu_parity.py runs it through every test).
+// What tools/micro/valu_rate3.hip measures: not every instruction costs the same -- add / sub / shift / and / or / compare /
 // select / v_bitop3 issue in ~2.5 cycles with two waves on the SIMD, the three-operand and byte instructions (v_and_or,
 // v_perm, v_dot4, SDWA, v_bfm, v_med3, v_bcnt, v_mul_u32_u24, v_readlane) in ~4.5, v_qsad_pk_u16_u8 in 17.  A tile of 64 reads
 // cost ~8,500 such cycles, half of them in logic that only a read with an indel needs.  This generation spends fewer:
@@ -28,7 +32,8 @@
 //           selector, a zeroed code -> 31, any other code -> 0xFF (bit 7 marks the read for the careful loop, which adds
 //           its N calls).  The value shifted is the constant 1: a masked base adds bit 31, which nothing reads.  So a
 //           piece costs 16 SDWA shifts + 16 ds_add_u32 and ~25 other instructions, for every kind of read.
-//     The quality buffer is free after 1b and the base buffer after pass 2; the next tile's rows are requested then.
+//     The quality buffer is free after 1b: the next tile's quality rows are requested then, and its packed bases are loaded by
+//     the lanes into registers (the LDS only ever holds the MASKED bases of the tile being counted).
 //   * The wave's packed window (one 32-bit word per reference position: T A C G counters of 8 8 8 7 bits + the bit the
 //     masked bases hit, 4 replicas) is folded into the block's 32-bit window every 7 tiles at the latest.
 // Results (new CIGAR, position, flags, counts, insertion events) are bit-identical to the other variants: same closed
@@ -79,16 +84,6 @@ __device__ __forceinline__ void dma_q_rows(const void *ge, const void *go, uint3
                  "global_load_lds_dwordx4 %1, off offset:128"
                  : : "v"(ge), "v"(go), "s"(lds) : "memory", "m0");
 }
-// the five instructions of its rows of packed bases: instruction c moves 16 bytes from g + 16 c to lds + 1024 c + 16 lane
-__device__ __forceinline__ void dma_s_rows(const void *g, uint32_t lds_) {
-    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, off\n\ts_add_u32 m0, m0, 1008\n\tglobal_load_lds_dwordx4 %0, off offset:16\n\ts_add_u32 m0, m0, 1008\n\t"
-                 "global_load_lds_dwordx4 %0, off offset:32\n\ts_add_u32 m0, m0, 1008\n\tglobal_load_lds_dwordx4 %0, off offset:48\n\ts_add_u32 m0, m0, 1008\n\t"
-                 "global_load_lds_dwordx4 %0, off offset:64"
-                 : : "v"(g), "s"(lds) : "memory", "m0");
-}
-
 // 16 failing-window bits of a piece for windows of 4: bit b <=> bytes b .. b+3 of (q, nx) sum to < thr (nthr = 65536 - thr in every half)
 __device__ __forceinline__ uint32_t f6_fail16_w4(const uint4 &q, uint32_t nx, uint64_t nthr) {
     const uint64_t s0 = __builtin_amdgcn_qsad_pk_u16_u8((uint64_t)q.x | ((uint64_t)q.y << 32), 0u, nthr);
@@ -311,7 +306,6 @@ k_fast6(F6_PARAMS) {
     const uint32_t rep = ((uint32_t)lane >> 1) & (uint32_t)(F6_REP - 1);
     const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F6_REPW * 4));
     const uint32_t qb_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u8 *)s_q[wave]);
-    const uint32_t sb_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u8 *)s_s[wave]);
     const lds_u8 *const qrow = (const lds_u8 *)s_q[wave] + 1024 * (lane >> 5) + 32 * (lane & 31);      // + 2048 (p >> 1) + 16 (p & 1): piece p of the lane's row
     lds_u8 *const srow8 = (lds_u8 *)s_s[wave] + 8 * lane;            // + 512 p: masked piece p
     const uint32_t one = 1u;
