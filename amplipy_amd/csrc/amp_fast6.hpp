@@ -696,12 +696,7 @@ k_fast6(F6_PARAMS) {
         F6_STAMP(4);          // pass 1b
         // the read's results (pass 2 lies between these stores and the next wait for loads)
         if (stored && !(AMP_F6_ABL & 32)) store_results((uint32_t)i, h.c0, ncig, cw, ts.pos, reflen, ts.err ? 0u : ts.flags, (uint32_t)ts.err);
-        // ---- requests, second half: the next tile's CIGAR words and quality rows, the list entries of the tile three ahead --------
-        const uint32_t tk3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk3v);
-        const Cg c1w = load_cig(h1, tk1 >= nTS);
-        if (tk1 < n_tb && !(AMP_F6_ABL & 16)) issue_q(h1);
-        const F6Hdr h2 = pack_hdr(r2, e2);
-        const uint32_t e3 = entry_of(tk3);
+        const F6Hdr h2 = pack_hdr(r2, e2);          // (the header of the tile after the next has arrived: packed, its seven registers are free)
         // ---- the ends of the counted ranges: the pieces that hold them are masked to the range ----------------------------------
         int32_t jb = 0; uint2 bsq = make_uint2(0u, 0u);                 // (indel tiles) the part of the second range that shares a piece with the first
         bool has_b = false;
@@ -804,7 +799,12 @@ k_fast6(F6_PARAMS) {
             }
         }
         wave_sync();
-        // (the next tile's packed bases: asked for here, behind the register-hungry part of the turn; pass 2 covers the wait)
+        // ---- requests, second half: the next tile's CIGAR words, quality rows (the buffer is free since pass 1b) and packed bases,
+        // the list entries of the tile three ahead -- asked for here, behind the register-hungry part of the turn; pass 2 covers the wait
+        const uint32_t tk3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk3v);
+        const Cg c1w = load_cig(h1, tk1 >= nTS);
+        if (tk1 < n_tb && !(AMP_F6_ABL & 16)) issue_q(h1);
+        const uint32_t e3 = entry_of(tk3);
         SRaw sr1 = sr0;
         if (!(AMP_F6_ABL & 16)) sr1 = load_s(h1);
         F6_STAMP(5);          // requests, range ends, (indel tiles: deletions, events)

@@ -1020,6 +1020,12 @@ int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kern
     return AMP_OK;
 }
 
+int amp_fast_path_active(amp_ctx *c) {
+    if (!c) return AMP_EINVAL;
+    const int kv = c->kernel_variant;
+    return ((kv == 0 || kv >= 4) && c->window <= 8 && c->min_quality <= 128) ? 1 : 0;
+}
+
 int amp_set_cu_share(amp_ctx *c, int divisor) {
     if (!c || divisor < 1 || divisor > 16) return AMP_EINVAL;
     c->cu_share = divisor;

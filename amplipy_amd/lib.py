@@ -27,7 +27,7 @@ EXPORTS = [
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
     "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events", "amp_set_cu_share",
-    "amp_aggregate_ins_events",
+    "amp_aggregate_ins_events", "amp_fast_path_active",
 ]
 
 
@@ -114,6 +114,13 @@ class Engine:
     def set_params(self, min_quality=20, window=4, do_trim=True, do_count=True):
         self._chk(self.L.amp_set_params(self.h, C.c_int32(min_quality), C.c_int32(window), C.c_int32(int(do_trim)),
                                         C.c_int32(int(do_count))), "amp_set_params")
+
+    def fast_path_active(self):
+        """True when runs with the current parameters take a fast kernel (windows of 1..8, min_quality <= 128)."""
+        rc = self.L.amp_fast_path_active(self.h)
+        if rc < 0:
+            self._chk(rc, "amp_fast_path_active")
+        return rc == 1
 
     def set_kernel_variant(self, v):
         self._chk(self.L.amp_set_kernel_variant(self.h, C.c_int(v)), "amp_set_kernel_variant")

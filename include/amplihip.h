@@ -257,6 +257,10 @@ int amp_reserve_events(amp_ctx *ctx, int64_t cap);
  * kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks (all give
  * identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
+/* 1 when runs with the ctx's current parameters take a fast kernel (window 1..8, min_quality <= 128, variant 0 / 4 / 5 / 6), 0 when
+ * every read takes the general tile kernel (same results, about 1.5 x the time); negative on a bad ctx.  Informational: lets a
+ * caller that sweeps sliding-window widths know when it has left the fast path (AmpliPy.py:563 takes any width). */
+int amp_fast_path_active(amp_ctx *ctx);
 /* Size the fast kernel's grid for 1 / divisor of the GPU's CUs (1, the default: one block per CU).  For callers that keep
  * several batches in flight on different streams (one ctx each): two passes side by side on half the chip each finish
  * sooner than one after the other on all of it -- a block then works twice as long, so its start-up, its flush and the idle

@@ -960,3 +960,22 @@ def test_begun_calls_are_cancelled_by_table_updates(scheme):
     assert np.array_equal(cons, cons2) and np.array_equal(vr, vr2) and np.array_equal(rel, rel2)
     assert vr.size and int(vr["total_depth"].max()) % 2 == 0
     e.close(); fresh.close()
+
+
+def test_fast_path_report(scheme):
+    """amp_fast_path_active (include/amplihip.h): windows of 1..8 and min_quality <= 128 run on the fast kernels, anything else on
+    the general tile kernel -- with the same results either way (a window of 12 against the oracle)."""
+    from amplipy_amd import lib
+    g, pr, amps, mn, mx, mpl = scheme
+    e = lib.Engine(g.size)
+    e.set_primers(mn, mx, mpl)
+    e.set_params(20, 4, True, True); assert e.fast_path_active()
+    e.set_params(20, 8, True, True); assert e.fast_path_active()
+    e.set_params(129, 4, True, True); assert not e.fast_path_active()
+    e.set_params(20, 12, True, True); assert not e.fast_path_active()
+    b = synth.make_amplicon_batch(g, amps, 20000, seed=33)
+    res = e.process(b)
+    a = oracle.process(b, g.size, mn, mx, mpl, 20, 12)
+    assert np.array_equal(res.new_pos, a.trim.new_pos) and np.array_equal(e.counts(), a.counts)
+    e.set_kernel_variant(2); assert not e.fast_path_active()
+    e.close()
