@@ -68,8 +68,11 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
 
 template <int W, int F5_WAVES, int F5_QRUN, int F5_REP, int F5_PW>
 __global__ void __launch_bounds__(F5_WAVES * 64, 2)
-k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *counts, EventBuf eb, uint32_t *glist, uint32_t *gcnt,
-        int reads_per_block) {
+k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_ARGS)
+    const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end, (uint32_t)a_epoch};
+    const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
+    const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
+    const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
     constexpr int F5_FLUSH = 255 / (64 / F5_REP);
     constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
@@ -238,6 +241,10 @@ k_fast5(KParams P, amp_dev_reads rd, uint64_t read_base, DevOut out, uint32_t *c
 
     uint32_t pw_lim = 0;
 
+    if (AMP_F_STAGGER > 0) {       // (wave w starts w steps late, as in k_fast)
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)AMP_F_STAGGER * (unsigned)wave;
+        while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- prologue: three tiles' headers; CIGAR words of the first two; the first tile's qualities and table entries -----------
     uint32_t tk0 = take_ticket(), tk1 = take_ticket(), tk2 = take_ticket();
     int64_t i0 = rb + 64 * (int64_t)tk0, i1 = rb + 64 * (int64_t)tk1, i2 = rb + 64 * (int64_t)tk2;
@@ -634,7 +641,7 @@ static inline int fast5_launch(const KParams &P, const amp_dev_reads &rd, uint64
                                const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, const Fast5Cfg &cf, hipStream_t stream) {
     const unsigned g = (unsigned)fg.grid;
     const int rpb = (int)fg.rpb;
-#define AMP_F5_GO(w, wv, qr, rp, pw) k_fast5<w, wv, qr, rp, pw><<<g, wv * 64, 0, stream>>>(P, rd, read_base, out, counts, eb, glist, gcnt, rpb)
+#define AMP_F5_GO(w, wv, qr, rp, pw) k_fast5<w, wv, qr, rp, pw><<<g, wv * 64, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb))
     if (cf.waves == 6) AMP_F5_GO(4, 6, 13312, 2, 512);
     else if (cf.waves == 4) AMP_F5_GO(4, 4, 19456, 4, 512);
     else switch (P.window) {
