@@ -1,86 +1,65 @@
-// amp_fast5.hpp -- the fast kernel, second generation (variant 5, the default): trim + pileup of the reads whose CIGAR has
-// the shape [S a][M m1]([I|D k][M m2])[S c], one lane per read, every byte of the batch loaded once.  CDNA4 / gfx950.
+// amp_fast7.hpp -- the fast kernel for batches of MIXED read lengths (variant 7): k_fast5's tile code (amp_fast5.hpp) driven
+// by per-block lists of reads binned by length, so that a tile's piece loops run to the length of ITS reads and no lane is
+// spent on a read that goes to the general pass.  CDNA4 / gfx950.
 //
-// Same decomposition as amp_fast.hpp (variant 4: a wave takes a TILE of 64 consecutive reads of the sorted batch, lane =
-// read, closed-form trims from amp_read.hpp, packed per-wave counter windows in LDS) with a leaner instruction stream.
-// What the counters of variant 4 showed (profiles/r03_*): the kernel is bound by instruction issue -- a wave issues one
-// instruction per ~4.4 cycles, a tile cost ~4,300 of them, two waves per SIMD slow each other by a quarter in EVERY
-// phase -- not by HBM, LDS or the I-cache.  So this version spends instructions, not bytes:
-//   * a tile's qualities AND packed bases arrive by LDS-DMA in two staging buffers and are consumed from there, 16 bases
-//     (a PIECE) at a time: no register copy of the read (60 VGPRs in variant 4), no register-staged base bytes, no LDS
-//     write + read-back of the bases
-//   * one pass over the qualities turns every piece into 16 failing-window bits + 16 "quality >= min_quality" bits
-//     (one VGPR per piece); the staging buffer is then free for the next tile's qualities while the bases are counted
-//   * the counted-base test, the range mask and the counter shift of a piece are computed from those bits with byte
-//     tricks that need no per-base work besides the SDWA shift + ds_add pair; codes outside A C G T are found with one
-//     popcount / has-zero-nibble test per piece (pad nibbles of the staged rows are patched to a valid code first)
-//   * every vector-memory operation of the loop that returns data is issued by inline assembly or as a plain load that
-//     is first touched behind the ONE wait at the top of the loop, so the compiler never drains the prefetches early
-//     (its wait-count pass answers a touched in-flight register with vmcnt(0)): the loop has two full drains, both of
-//     loads issued a phase or more before (top: next qualities, primer-table entries, CIGAR words, header;
-//     before counting: this tile's bases)
-//   * results are stored in the tile they belong to (no one-tile deferral, no packed `pending' registers)
-// Reads it does not take (other CIGARs, QUAL '*', more than F5_MAXLEN bases, rows that do not fit the staging buffer)
-// go on the block's list for the general pass, exactly as in variant 4.
+// What k_fast5 does on BASELINE config 5 (75-300 bp reads, 40 % of them for the general pass): a tile is 64 CONSECUTIVE
+// reads, its loops run to the longest of them (300 bases in practically every tile) and 43 % of its lanes hold reads it
+// hands over: 36 % of the lane-slots do work.  Here a block first walks the headers of its reads once and
+// writes four lists into its segment of `clist` (scratch): reads of up to 80 / 144 / 224 / 304 bases whose CIGAR can have
+// the closed-form shape (at most five ops, soft clips where a five- or four-op shape needs them); everything else goes on
+// the general list at once.  Tiles are then cut from the lists, longest bin first:
+//   bins 0 and 1: 64 reads, lane = read, 6 / 10 piece slots
+//   bins 2 and 3: 32 reads, TWO lanes per read (lane 2r takes the first 8 / 10 pieces of read r, lane 2r + 1 the others):
+//     the rows of 64 reads of 304 bases do not fit a wave's share of the LDS next to seven other waves, the rows of 32 do,
+//     and the piece loops are half as long.  Both lanes compute the read's trims (same inputs, same result); the first
+//     failing window is the minimum over the pair; results, indel extras and hand-overs are lane 2r's.
+// A tile's rows are gathered by LDS-DMA into a row-major image with a stride per bin (a multiple of 16 bytes: lane l of
+// instruction s moves image bytes [1024 s + 16 l, + 16), which lie in ONE row); everything behind the staging buffers is
+// amp_fast5.hpp's code with a lane's first piece (`pbase`) added to its piece numbers.
 #pragma once
 
-#include "amp_fast.hpp"
-#include "amp_bf.hpp"
+#include "amp_fast5.hpp"
+#include "amp_fast6.hpp"
 
 namespace amp {
 
-#ifndef AMP_F5_ABL
-#define AMP_F5_ABL 0      // development builds: parts of the kernel switched off to count the rest's instructions (results are wrong on purpose)
+#ifndef AMP_F7_ABL
+#define AMP_F7_ABL 0
 #endif
-constexpr int F5_NP = 20;                 // 16-base pieces of the longest read taken
-constexpr int F5_MAXLEN = 304;            // F5_NP pieces cover it from 8 bases before its start
-constexpr int F5_PAD = 16;                // bytes in front of / behind a staged run
-// Three builds of the kernel (template parameters WAVES, QRUN, REP; one block per CU, all of its LDS):
-//   8 waves, runs of 9,728 quality bytes (64 reads of up to 152 padded bases: every tile of a 150 bp run fits), packed
-//     windows of 256 positions in 4 replicas
-//   6 waves, runs of 13,312 bytes (64 reads of 208 padded bases on average), windows of 512 positions (a read of 300 bases
-//     does not fit 256) in 2 replicas
-//   4 waves, runs of 19,456 bytes (64 reads of 304 padded bases: every tile of reads the kernel takes fits), 512 positions
-//     in 4 replicas
-// The host picks by the batch's mean padded read length; reads of a tile that do not fit its run go to the general pass.
-// A counter byte gets at most 64 / REP increments per tile (a read covers a position once): the window is folded every
-// 255 / (64 / REP) tiles at the latest.
-// (Four replicas instead of variant 4's eight: two-way bank conflicts cost nothing, the LDS takes four cycles to receive an
-// atomic's operands anyway.)
+constexpr int F7_WAVES = 8;
+constexpr int F7_QCAP = 9728;             // bytes of a tile's quality image (64 x 144, 32 x 304)
+constexpr int F7_SCAP = 5120;             // ... of its packed-base image (64 x 80, 32 x 160)
+constexpr int F7_REP = 2, F7_PW = 448;    // packed window: positions, replicas (a read of 304 bases + 16 in front + the spread of a tile's starts)
+constexpr int F7_NBIN = 4;
 
-// LDS-DMA of 16 bytes per lane, issued where the compiler cannot see it (see the head of the file)
-__device__ __forceinline__ void dma16(const void *g, const lds_u8 *l) {
-    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)l);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory", "m0");
+// one of four 16-bit / 32-bit constants by a bin number (shifts of packed words: a chain of selects becomes a table in scratch
+// memory, and every load from it makes the wave wait for all of its loads in flight)
+__device__ __forceinline__ uint32_t f7_pick16(uint32_t b, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    const uint64_t w = (uint64_t)v0 | ((uint64_t)v1 << 16) | ((uint64_t)v2 << 32) | ((uint64_t)v3 << 48);
+    return (uint32_t)(w >> (16u * b)) & 0xFFFFu;
 }
-
-// OR over the lanes of the wave (DPP row shifts and row broadcasts; the result is uniform)
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
-    uint32_t t = x;
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xF, 0xF, true);      // row_shr:1
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xF, 0xF, true);      // row_shr:2
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, true);      // row_shr:4
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, true);      // row_shr:8
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
-    t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
+__device__ __forceinline__ uint32_t f7_pick32(uint32_t b, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    const uint64_t lo = (uint64_t)v0 | ((uint64_t)v1 << 32), hi = (uint64_t)v2 | ((uint64_t)v3 << 32);
+    return (uint32_t)(((b & 2u) ? hi : lo) >> (32u * (b & 1u)));
 }
+__device__ __forceinline__ uint32_t f7_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-template <int W, int F5_WAVES, int F5_QRUN, int F5_REP, int F5_PW>
-__global__ void __launch_bounds__(F5_WAVES * 64, 2)
-k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_ARGS)
+template <int W>
+__global__ void __launch_bounds__(F7_WAVES * 64, 2)
+k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments, like k_fast: see the note at F_ARGS)
+    constexpr int F5_WAVES = F7_WAVES, F5_REP = F7_REP, F5_PW = F7_PW;
     const KParams P{a_min_quality, a_window, a_do_trim, a_do_count, a_ref_len, a_max_primer_len, a_min_start, a_max_end, (uint32_t)a_epoch};
     const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
     const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
     const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
     constexpr int F5_FLUSH = 255 / (64 / F5_REP);
-    constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
+    constexpr int F5_QB = F5_PAD + F7_QCAP + 2 * F5_PAD, F5_SB = F5_PAD + F7_SCAP + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the image)
     __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
     __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
     __shared__ uint32_t s_pwin[F5_WAVES][F5_REP * F5_REPW];           // per wave: packed counters, byte c of a word = base c (A C G T)
     __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
-    __shared__ uint32_t s_ticket, s_gcur;
+    __shared__ uint32_t s_ticket, s_gcur, s_nb[F7_NBIN];
     unsigned long long *const ctr = eb.ctr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t n = rd.n_reads;
@@ -93,7 +72,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     // every nibble of the base staging buffer starts as a valid code (the bytes in front of a run are read by the
     // lanes whose pieces start 8 bases early, and are never written again)
     for (int i = lane; i < F5_SB / 4; i += 64) ((lds_u32 *)s_s[wave])[i] = 0x11111111u;
-    if (tid == 0) { s_ticket = 0; s_gcur = 0; }
+    if (tid == 0) { s_ticket = 0; s_gcur = 0; s_nb[0] = 0; s_nb[1] = 0; s_nb[2] = 0; s_nb[3] = 0; }
     if (tid == 0 && blockIdx.x == 0) { eb.ctr[26] = 0ull; eb.ctr[27] = 0ull; eb.ctr[28] = 0ull; }      // k_gcompact / k_long's counters (amp_wave.hpp)
     int32_t bw_base = rb < n ? rd.pos[rb] : 0;
     bw_base = (bw_base < 16 ? 0 : bw_base - 16) & ~15;
@@ -104,7 +83,56 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     const uint32_t thr = mqc * (uint32_t)W;
     const uint32_t mqb = (uint32_t)mq * 0x01010101u;             // mq <= 128 (the host sends other runs to the general kernel)
     const uint32_t G = (uint32_t)P.ref_len;
-    const uint32_t n_tb = re > rb ? (uint32_t)((re - rb + 63) / 64) : 0u;
+    const uint32_t q_tot8 = rd.seq_off8[n];                          // rows end here (units of 8 bases): 16 bytes of slack behind
+    // ---- bins: the block's reads by length (A:426-753 do not care about the order of reads).  The block's segment of clist is
+    // two stretches of reads_per_block entries: bins 0 / 1 fill the first from its front / back, bins 2 / 3 the second; reads
+    // that cannot have the closed-form shape go on the general list at once.  (The order inside a list is the order in which
+    // the waves' groups of 64 reads arrive: a tile does not rely on it.)
+    uint32_t *const seg = clist + 2 * rb;
+    {
+        constexpr int R = 4;                                       // groups of 64 reads whose loads are in flight together
+        for (int64_t g0 = rb + (int64_t)wave * 64; g0 < re; g0 += (int64_t)R * F7_WAVES * 64) {
+            uint32_t c0[R], c1[R], ls[R], wf[R], wl[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t i = g0 + (int64_t)r * F7_WAVES * 64 + lane;
+                const int64_t ic = i < re ? i : rb;
+                c0[r] = rd.cig_off32[ic]; c1[r] = rd.cig_off32[ic + 1]; ls[r] = rd.lseq[ic];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {      // first and last CIGAR word of the reads with four or five ops: such a shape needs soft clips
+                const uint32_t nops = c1[r] - c0[r];
+                const bool want = nops == 4u || nops == 5u;
+                wf[r] = want ? rd.cig[c0[r]] : 4u; wl[r] = want ? rd.cig[c1[r] - 1u] : 4u;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t i = g0 + (int64_t)r * F7_WAVES * 64 + lane;
+                const bool valid = i < re;
+                const uint32_t nops = c1[r] - c0[r];
+                const bool sf = (wf[r] & 15u) == OP_S, sl = (wl[r] & 15u) == OP_S;
+                const bool cand = ls[r] >= 1u && ls[r] <= (uint32_t)F5_MAXLEN && nops >= 1u && nops <= 5u && (nops < 4u || (nops == 4u ? (sf | sl) : (sf & sl)));
+                const uint32_t cls = !valid ? 5u : !cand ? 4u : ls[r] <= 80u ? 0u : ls[r] <= 144u ? 1u : ls[r] <= 224u ? 2u : 3u;
+#pragma unroll
+                for (uint32_t c = 0; c < 5u; ++c) {
+                    const unsigned long long m = __ballot(cls == c);
+                    if (!m) continue;
+                    uint32_t base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(c == 4u ? (lds_u32 *)&s_gcur : (lds_u32 *)&s_nb[c], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (cls == c) {
+                        if (c == 4u) glist[(size_t)rb + at] = (uint32_t)i;
+                        else seg[(c >> 1) * (uint32_t)reads_per_block + ((c & 1u) ? (uint32_t)reads_per_block - 1u - at : at)] = (uint32_t)i;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // tiles, longest bin first: tiles [0, t3) of bin 3, [t3, t2) of bin 2 (32 reads each), [t2, t1) of bin 1, [t1, n_tb) of bin 0
+    const uint32_t nb0 = s_nb[0], nb1 = s_nb[1], nb2 = s_nb[2], nb3 = s_nb[3];
+    const uint32_t t3 = (nb3 + 31u) >> 5, t2 = t3 + ((nb2 + 31u) >> 5), t1 = t2 + ((nb1 + 63u) >> 6), n_tb = (AMP_F7_ABL & 4) ? 0u : t1 + ((nb0 + 63u) >> 6);
     auto take_ticket = [&]() {
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -159,26 +187,38 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     struct Hdr { int32_t pos, tlen; uint32_t lseq, flag, c0, c1, o8; };      // as loaded
     // ... and as kept: lf = l_seq (saturated at 0xFFFF) | paired << 16 | reverse << 17 | the template-length test of A:452 << 18 |
     // number of CIGAR ops (saturated at 7) << 19 | lane holds a read of the block << 22
-    struct HdrP { int32_t pos; uint32_t lf, c0, o8;
+    struct HdrP { int32_t pos; uint32_t lf, c0, o8, idx;      // idx: the read (a lane without one points at the block's first read)
         __device__ uint32_t lseq() const { return lf & 0xFFFFu; }
         __device__ uint32_t nops() const { return (lf >> 19) & 7u; }
         __device__ uint32_t flag() const { return ((lf >> 16) & 1u) | (((lf >> 17) & 1u) << 4); }
         __device__ bool isize_flag() const { return (lf >> 18) & 1u; }
         __device__ bool valid() const { return (lf >> 22) & 1u; } };
-    auto load_hdr = [&](int64_t t0) {
-        Hdr h{0, 0, 0u, 0u, 0u, 0u, 0u};
-        const int64_t i = t0 + lane;
-        if (i < re) {
-            h.pos = rd.pos[i]; h.flag = rd.flag[i]; h.tlen = rd.tlen[i]; h.lseq = rd.lseq[i];
-            h.c0 = rd.cig_off32[i]; h.c1 = rd.cig_off32[i + 1]; h.o8 = rd.seq_off8[i];
-        }
+    // tile tk: its bin, and the list entry of the lane (read index; 0xFFFFFFFF = none).  Tiles of bins 2 and 3 hold 32 reads,
+    // two lanes each.
+    auto bin_of = [&](uint32_t tk) -> uint32_t { return 3u - (tk >= t3 ? 1u : 0u) - (tk >= t2 ? 1u : 0u) - (tk >= t1 ? 1u : 0u); };
+    auto entry_of = [&](uint32_t tk) -> uint32_t {
+        const uint32_t b = bin_of(tk);
+        const uint32_t first = f7_pick32(b, t1, t2, t3, 0u), cnt = f7_pick32(b, nb0, nb1, nb2, nb3);      // (by value: a select between captured variables is a select between their addresses, and puts them in scratch memory)
+        const uint32_t ln = f7_lane();
+        const uint32_t j = b >= 2u ? (tk - first) * 32u + (ln >> 1) : (tk - first) * 64u + ln;
+        const bool valid = tk < n_tb && j < cnt;
+        const uint32_t at = (b >> 1) * (uint32_t)reads_per_block + ((b & 1u) ? (uint32_t)reads_per_block - 1u - j : j);
+        const uint32_t e = seg[valid ? at : 0u];
+        return valid ? e : 0xFFFFFFFFu;
+    };
+    auto load_hdr = [&](uint32_t ent) {
+        const int64_t i = ent == 0xFFFFFFFFu ? rb : (int64_t)ent;
+        Hdr h;
+        h.pos = rd.pos[i]; h.flag = rd.flag[i]; h.tlen = rd.tlen[i]; h.lseq = rd.lseq[i];
+        h.c0 = rd.cig_off32[i]; h.c1 = rd.cig_off32[i + 1]; h.o8 = rd.seq_off8[i];
         return h;
     };
-    auto pack_hdr = [&](const Hdr &h, int64_t t0) {
+    auto pack_hdr = [&](const Hdr &h, uint32_t ent) {
         const uint32_t nn = h.c1 - h.c0, at = (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen);
         const bool isz = ((int64_t)at - P.max_primer_len) > (int64_t)h.lseq;                                  // A:452
+        const bool valid = ent != 0xFFFFFFFFu;
         return HdrP{h.pos, (h.lseq > 0xFFFFu ? 0xFFFFu : h.lseq) | ((h.flag & 1u) << 16) | (((h.flag >> 4) & 1u) << 17) | ((isz ? 1u : 0u) << 18) |
-                               ((nn > 7u ? 7u : nn) << 19) | ((t0 + lane < re ? 1u : 0u) << 22), h.c0, h.o8};
+                               ((nn > 7u ? 7u : nn) << 19) | ((valid ? 1u : 0u) << 22), h.c0, h.o8, valid ? ent : (uint32_t)rb};
     };
     struct Cg { uint32_t w[5]; };
     auto load_cig = [&](const HdrP &h) {
@@ -190,26 +230,24 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         }
         return c;
     };
-    // the tile's run: the bytes of its leading reads that fit the staging buffer (64 reads of up to 152 bases always do)
-    struct Geo { uint32_t np, row, Tq, m0; int ntake; bool solo, fastq; };
-    auto geometry = [&](const HdrP &h) {
+    // a tile's geometry: row = offset of the lane's row in the quality image (the packed bases' image has rows of srow bytes),
+    // np = pieces of the LANE, pbase = its first piece, half = the second lane of a pair
+    struct Geo { uint32_t np, pbase, row, srow, bin; bool half, fastq; };
+    auto geometry = [&](const HdrP &h, uint32_t tk) {
         Geo g;
-        const bool valid = h.valid();
-        const uint32_t hl = h.lseq();
-        const bool shortq = valid && hl >= 1u && hl <= (uint32_t)F5_MAXLEN;
-        g.np = shortq ? (hl + phi_lane + 15u) >> 4 : 1u;
-        g.m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.o8);
-        g.row = (h.o8 - g.m0) * 8u;
-        const uint32_t nch = (hl + 7u) >> 3;
-        // a row is read as pieces of 16 bytes plus the 8 bytes behind them: up to 24 bytes past the read's own padded bytes
-        const bool fits = valid && h.o8 >= g.m0 && (h.o8 - g.m0) <= (uint32_t)(F5_QRUN / 8) && g.row + 8u * nch <= (uint32_t)F5_QRUN;
-        const unsigned long long fitmask = __ballot(fits);
-        g.ntake = fitmask == ~0ull ? 64 : __builtin_ctzll(~fitmask);
-        g.solo = g.ntake == 0;
-        if (g.solo) g.ntake = 1;
-        g.Tq = g.solo ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)(g.row + 8u * nch), g.ntake - 1);
-        g.fastq = lane < g.ntake && !g.solo && shortq;
-        if (!g.fastq) { g.row = 0u; g.np = 1u; }
+        g.bin = bin_of(tk);
+        const bool pair = g.bin >= 2u;
+        const uint32_t qs = f7_pick16(g.bin, 80u, 144u, 224u, 304u);
+        const uint32_t ss = f7_pick16(g.bin, 48u, 80u, 112u, 160u);
+        const uint32_t na = 8u + (g.bin & 1u) * 2u;                 // pieces of a pair's first lane (bin 2: 8, bin 3: 10)
+        const uint32_t r = pair ? (uint32_t)lane >> 1 : (uint32_t)lane;
+        g.half = pair && (lane & 1);
+        g.fastq = h.valid();
+        const uint32_t npt = (h.lseq() + phi_lane + 15u) >> 4;      // pieces of the read (bins 2 / 3: more than na, by their lengths)
+        g.np = !g.fastq ? 1u : !pair ? npt : g.half ? npt - na : na;
+        g.pbase = g.half && g.fastq ? na : 0u;
+        g.row = g.fastq ? r * qs : 0u;
+        g.srow = g.fastq ? r * ss : 0u;
         return g;
     };
     struct Shape { Bf s; bool ok; int32_t refspan; };
@@ -228,14 +266,24 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         if (sh.ok & (P.do_trim != 0) & in_ref) { t.L = P.max_end[h.pos]; t.R = P.min_start[h.pos + sh.refspan - 1]; }
         return t;
     };
-    // LDS-DMA of a run: lane l moves bytes [1024 s + 16 l, + 16) to the same offset of the staging buffer; lanes past the
-    // run re-read its end, lanes past the buffer do nothing
-    auto issue_run = [&](const uint8_t *run, uint32_t nbytes, lds_u8 *stage, int cap) {
-        const uint32_t last = nbytes ? (nbytes - 1u) & ~15u : 0u;
-#pragma unroll
-        for (int sl = 0; sl < (cap + 1023) / 1024; ++sl) {
-            uint32_t off = (uint32_t)(sl * 1024 + lane * 16);
-            if (sl * 1024 + 1024 <= cap || (int)off < cap) dma16(run + (off < last ? off : last), stage + sl * 1024);
+    // LDS-DMA of a tile's rows: lane l of instruction s moves bytes [1024 s + 16 l, + 16) of the row-major image; they belong
+    // to ONE row (strides are multiples of 16), whose address comes from the lane that holds the row.  unit = bytes per 8
+    // bases (8: qualities, 4: packed bases).  Bytes of a row behind the end of the batch's buffer are fetched from its end
+    // (16 bytes of slack); they lie behind the read's own bytes.
+    auto issue_rows = [&](const uint8_t *base, uint32_t unit, const HdrP &h, uint32_t bin, bool bases, lds_u8 *stage) {
+        const bool pair = bin >= 2u;
+        const uint32_t stride = bases ? f7_pick16(bin, 48u, 80u, 112u, 160u) : f7_pick16(bin, 80u, 144u, 224u, 304u);
+        const uint32_t magic = bases ? f7_pick32(bin, 89478486u, 53687092u, 38347923u, 26843546u)
+                                     : f7_pick32(bin, 53687092u, 29826162u, 19173962u, 14128182u);      // ceil(2^32 / stride)
+        const uint32_t ln16 = f7_lane() * 16u;
+        const uint32_t nbytes = (pair ? 32u : 64u) * stride;
+        const int ninst = (AMP_F7_ABL & 2) ? 0 : (int)((nbytes + 1023u) >> 10);
+        for (int sl = 0; sl < ninst; ++sl) {
+            const uint32_t off0 = (uint32_t)(sl * 1024) + ln16, off = off0 < nbytes ? off0 : nbytes - 16u;
+            const uint32_t row = __umulhi(off, magic), within = off - row * stride;
+            const uint32_t o8 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pair ? row * 2u : row) * 4u), (int)h.o8);      // (all lanes take part: a lane that is switched off hands out nothing)
+            const uint32_t lim = (q_tot8 - o8) * unit;
+            if (off0 < nbytes) dma16(base + (int64_t)o8 * unit + (within < lim ? within : lim), stage + sl * 1024);      // (lanes past the image: the staging buffer ends there)
         }
     };
 
@@ -246,21 +294,24 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(8);
     }
     // ---- prologue: three tiles' headers; CIGAR words of the first two; the first tile's qualities and table entries -----------
-    uint32_t tk0 = take_ticket(), tk1 = take_ticket(), tk2 = take_ticket();
-    int64_t i0 = rb + 64 * (int64_t)tk0, i1 = rb + 64 * (int64_t)tk1, i2 = rb + 64 * (int64_t)tk2;
+    // (tickets run four tiles ahead: the list entries of tile t + 4 are asked for while tile t is computed, the headers of t + 3)
+    uint32_t tk0 = take_ticket(), tk1 = take_ticket(), tk2 = take_ticket(), tk3 = take_ticket();
     HdrP h0, h1;
     Hdr hR;
+    uint32_t eR, eN;                               // list entries of the tile whose header is in hR / of the tile behind it
     {
-        const Hdr a = load_hdr(i0), b = load_hdr(i1);
-        hR = load_hdr(i2);
-        h0 = pack_hdr(a, i0); h1 = pack_hdr(b, i1);
+        const uint32_t e0 = entry_of(tk0), e1 = entry_of(tk1);
+        eR = entry_of(tk2); eN = entry_of(tk3);
+        const Hdr a = load_hdr(e0), b = load_hdr(e1);
+        hR = load_hdr(eR);
+        h0 = pack_hdr(a, e0); h1 = pack_hdr(b, e1);
     }
     Cg cN = load_cig(h1);
-    Geo g0 = geometry(h0);
+    Geo g0 = geometry(h0, tk0);
     Shape sh0;
     {
         const Cg c = load_cig(h0);
-        issue_run(rd.qual + (int64_t)g0.m0 * 8, g0.Tq, qst, F5_QRUN);
+        issue_rows(rd.qual, 8u, h0, g0.bin, false, qst);
         sh0 = shape_of(h0, c, g0.fastq);
     }
     Tabs tb0 = load_tabs(h0, sh0);
@@ -273,24 +324,25 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         // (every register a load of the last turn -- or of the prologue -- wrote is touched HERE, where nothing is in flight: left to its
         // own devices the compiler waits at the first use, behind the issue of this tile's bases, and the wave sits out their latency)
         asm volatile("" : : "v"(tb0.L), "v"(tb0.R), "v"(cN.w[0]), "v"(cN.w[1]), "v"(cN.w[2]), "v"(cN.w[3]), "v"(cN.w[4]));
-        asm volatile("" : : "v"(hR.pos), "v"(hR.tlen), "v"(hR.lseq), "v"(hR.flag), "v"(hR.c0), "v"(hR.c1), "v"(hR.o8));
+        asm volatile("" : : "v"(hR.pos), "v"(hR.tlen), "v"(hR.lseq), "v"(hR.flag), "v"(hR.c0), "v"(hR.c1), "v"(hR.o8), "v"(eN), "v"(eR));
         const HdrP h = h0;
         const Geo g = g0;
         const Shape shp = sh0;
         const Tabs tA = tb0;
-        const Geo g1 = geometry(h1);
+        const Geo g1 = geometry(h1, tk1);
         const Shape sh1 = shape_of(h1, cN, g1.fastq);
-        const HdrP h2 = pack_hdr(hR, i2);
+        const HdrP h2 = pack_hdr(hR, eR);
         // this tile's packed bases start moving (their buffer was in use until the end of the last tile)
-        issue_run(rd.seq + (int64_t)g.m0 * 4, g.Tq >> 1, sst, F5_QRUN / 2);
-        const int64_t i = i0 + lane;
+        issue_rows(rd.seq, 4u, h, g.bin, true, sst);
+        const int64_t i = (int64_t)h.idx;
+        const bool pair = g.bin >= 2u, mine = !g.half;                // (pair: uniform; mine: the lane that stores the read's results)
         const int32_t pos = h.pos;
         const uint32_t lseq = h.lseq(), flag = h.flag(), c0 = h.c0, o8 = h.o8;
         const uint32_t np = g.np, phi = g.fastq ? phi_lane : 0u;
         const bool fastq = g.fastq;
         // ---- the wave's packed window: fold and re-anchor when the tile has moved on, or before a byte could overflow
         {
-            const int32_t first_pos = __builtin_amdgcn_readfirstlane(pos);
+            const int32_t first_pos = wave_min_i32(fastq ? pos : 0x7FFFFFFF);      // (a list is not strictly in the order of the batch)
             const int32_t want = (first_pos < 16 ? 0 : first_pos - 16) & ~15;
             if (pw_tiles >= F5_FLUSH || want < pw_base || want - pw_base >= 64) {
                 if (pw_tiles) fold();
@@ -324,7 +376,8 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality), of which the
         // first / last inside [lo, hi - W] give the first failing window start (forward) / last failing window end
         // (reverse); and 16 good-quality bits, kept as ok[k] for the counting phase ------------------------------------------
-        const uint32_t rot = (uint32_t)lane % np;
+        const uint32_t rot = ((uint32_t)lane >> (pair ? 1 : 0)) % np;
+        const uint32_t pbase = g.pbase;
         const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
         const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
         const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
@@ -336,8 +389,8 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
             if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;             // (uniform)
             uint32_t p = (uint32_t)k + rot;
             p = p >= np ? p - np : p;
-            const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
-            p = (uint32_t)k < np ? p : np;
+            const uint32_t pa = pbase + ((uint32_t)k < np ? p : np - 1u);
+            p = (uint32_t)k < np ? pbase + p : 4096u;                          // (a slot the lane has no piece for: outside every range)
             const lds_u8 *src = qst + lrow + (int32_t)(pa * 16u);
             const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
             const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
@@ -349,6 +402,10 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 ffmin = ((fail != 0u) & (f1 < ffmin)) ? f1 : ffmin;
                 lemax = ((fail != 0u) & (e1 > lemax)) ? e1 : lemax;
             }
+        }
+        if (pair) {      // (uniform) the two lanes of a read have looked at different pieces
+            const int32_t fo_ = __builtin_amdgcn_update_dpp(0, ffmin, 0xB1, 0xF, 0xF, true), lo_ = __builtin_amdgcn_update_dpp(0, lemax, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+            ffmin = fo_ < ffmin ? fo_ : ffmin; lemax = lo_ > lemax ? lo_ : lemax;
         }
         const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
         // ---- quality clip (A:589-686) --------------------------------------------------------------------------------
@@ -379,7 +436,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         const bool stored = shaped & !nogo;
         const bool okres = stored & (terr == 0);
         const int32_t reflen = okres ? s.ref_len() : 0;
-        n_err += (stored & (terr != 0)) ? 1u : 0u;
+        n_err += (stored & mine & (terr != 0)) ? 1u : 0u;
         const bool counted = okres & (P.do_count != 0);
         // ---- what counting needs of the qualities besides the bits: the inserted bases' (A:730-748), and the good bits of
         // GROUP B = the 16 bases from the 8-aligned start of the second segment, for the piece that holds bases of both
@@ -403,7 +460,8 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
             // [S a][op m1][I|D k][op m2][S c], absent parts left out
             const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op, ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D),
                                       ((uint32_t)s.m2 << 4) | s.op, ((uint32_t)s.c << 4) | OP_S};
-            const bool has[5] = {bool(okres & (s.a > 0)), bool(okres & (s.m1 > 0)), bool(okres & (s.kind != 0)), bool(okres & (s.kind != 0) & (s.m2 > 0)), bool(okres & (s.c > 0))};
+            const bool okm_ = okres & mine;
+            const bool has[5] = {bool(okm_ & (s.a > 0)), bool(okm_ & (s.m1 > 0)), bool(okm_ & (s.kind != 0)), bool(okm_ & (s.kind != 0) & (s.m2 > 0)), bool(okm_ & (s.c > 0))};
             uint32_t *home = out.new_cig + ((size_t)c0 + 3 * (size_t)i);
             uint32_t nc = 0;
 #pragma unroll
@@ -411,7 +469,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 if (has[t]) home[nc] = part[t];
                 nc += has[t] ? 1u : 0u;
             }
-            if (stored) {
+            if (stored & mine) {
                 if (out.new_pos) out.new_pos[i] = tpos;
                 if (out.new_ncig) out.new_ncig[i] = nc;
                 if (out.ref_len) out.ref_len[i] = reflen;
@@ -419,28 +477,29 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 if (out.status) out.status[i] = (uint8_t)terr;
             }
         }
-        const uint32_t tk3 = take_ticket();
-        const int64_t i3 = rb + 64 * (int64_t)tk3;
-        issue_run(rd.qual + (int64_t)g1.m0 * 8, g1.Tq, qst, F5_QRUN);
+        const uint32_t tk4 = take_ticket();
+        issue_rows(rd.qual, 8u, h1, g1.bin, false, qst);
         tb0 = load_tabs(h1, sh1);
         cN = load_cig(h2);
-        hR = load_hdr(i3);
+        hR = load_hdr(eN);                         // (eN arrived before the wait at the top of this turn)
+        eR = eN;
+        eN = entry_of(tk4);
         {
-            // the next tile's packed bases are pulled into L2 now (one dword of every 128-byte line; plain loads whose values
-            // are only "used" behind the wait at the top of the loop): their LDS-DMA can only be issued when this tile's bases
-            // have been counted, a third of a tile before they are needed
-            const uint32_t nb = g1.Tq >> 1;
-            const uint32_t off = (uint32_t)lane * 128u;
-            const uint8_t *sb = rd.seq + (int64_t)g1.m0 * 4;
-            pfA = *(const uint32_t *)(sb + (off < nb ? off : 0u));
-            if (F5_QRUN / 2 > 8192) pfB = *(const uint32_t *)(sb + (off + 8192u < nb ? off + 8192u : 0u));
+            // the next tile's packed bases are pulled into L2 now (the 128-byte lines of the lane's row -- a pair shares them out;
+            // plain loads whose values are only "used" behind the wait at the top of the loop): their LDS-DMA can only be issued
+            // when this tile's bases have been counted, a third of a tile before they are needed
+            const uint32_t lim = (q_tot8 - h1.o8) * 4u;
+            const uint32_t off = g1.half ? 128u : 0u;
+            const uint8_t *sb = rd.seq + (int64_t)h1.o8 * 4;
+            pfA = *(const uint32_t *)(sb + (off < lim ? off : 0u));
+            pfB = *(const uint32_t *)(sb + (off + 64u < lim ? off + 64u : 0u));
         }
         // pad nibbles of the staged rows (a row is padded to 8 bases) become a valid code: the test for codes outside
         // A C G T looks at whole pieces
         {
-            const uint32_t e = fastq ? lseq & 7u : 0u;                        // bases of the row's last group of 8 (0: the group is full)
+            const uint32_t e = (fastq & mine) ? lseq & 7u : 0u;                // bases of the row's last group of 8 (0: the group is full)
             if (e) {
-                lds_u32 *w = (lds_u32 *)(sst + (g.row >> 1) + 4u * (lseq >> 3));
+                lds_u32 *w = (lds_u32 *)(sst + g.srow + 4u * (lseq >> 3));
                 // nibble i of the group sits in byte i >> 1, high nibble first
                 const uint32_t x = *w, xs = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);      // nibble i at bit 4 i
                 const uint32_t keep = (1u << (4u * e)) - 1u;
@@ -457,7 +516,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         const int32_t pos2 = tpos + s.m1 + s.kD();                                 // reference position of the second segment
         bool bad_extra = false;
         // deletion: '-' at each of its positions (A:714-715), through the block's window
-        if (two & (s.kind == 2) & !(AMP_F5_ABL & 4)) {
+        if (two & mine & (s.kind == 2) & !(AMP_F5_ABL & 4)) {
             for (int32_t j = 0; j < s.k; ++j) {
                 const int32_t r = tpos + s.m1 + j;
                 const uint32_t d = (uint32_t)(r - bw_base);
@@ -468,7 +527,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         }
         // insertion (A:730-748): one event per maximal run of good-quality inserted bases
         {
-            uint32_t runs = (AMP_F5_ABL & 4) ? 0u : good & ~(good << 1);                              // first base of every run
+            uint32_t runs = (AMP_F5_ABL & 4) || !mine ? 0u : good & ~(good << 1);                     // first base of every run
             const unsigned long long em = __ballot(runs != 0u);
             if (em) {
                 const uint32_t total = (uint32_t)__popcll(em);
@@ -513,13 +572,13 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F5_NP = group B
         // group B: the part of the second segment that shares a piece with the first
         const int32_t jstar = (qb1 - 1) & ~15;                       // the piece that holds the first segment's last base
-        const bool has_b = two & (jstar + 16 > qa2) & (qb2 > qa2);
+        const bool has_b = two & mine & (jstar + 16 > qa2) & (qb2 > qa2);
         const int32_t xbe = qb2 < jstar + 16 ? qb2 : jstar + 16;
         const int32_t jb = g_b + (int32_t)phi;
         // The bases go into the wave's packed window, F_PW positions from pw_base; a tile whose reads lie further apart (the
         // step from one pile of reads to the next) is counted in PASSES: fold, re-anchor at the first lane left.
         const int32_t end_pos = two ? pos2 + s.m2 : tpos + s.m1;                   // one past the last counted position
-        const lds_u8 *const lsrow = sst + (int32_t)(g.row >> 1) - (int32_t)(phi >> 1);
+        const lds_u8 *const lsrow = sst + (int32_t)g.srow - (int32_t)(phi >> 1);
         bool todo = counted;
         for (bool first_pass = true;; first_pass = false) {
             const unsigned long long tm = __ballot(todo);
@@ -537,7 +596,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
             const int32_t a1 = now ? qa1 : 0, b1 = now ? qb1 : 0, a2 = now ? qa2 : 0, b2 = now ? qb2 : 0;
             const int32_t dbase1 = tpos - pw_base - qa1, dbase2 = pos2 - pw_base - qa2;
             if (__ballot(has_b & now)) {
-                const lds_u8 *sp = sst + (g.row >> 1) + (uint32_t)(g_b >> 1);
+                const lds_u8 *sp = sst + g.srow + (uint32_t)(g_b >> 1);
                 const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
                 const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
                 redo |= count_piece5(sq, mB, dbase2 + jb, lim16, wrep) << F5_NP;
@@ -547,8 +606,8 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 if (!((live >> k) & 1u) || (AMP_F5_ABL & 2)) continue;
                 uint32_t p = (uint32_t)k + rot;
                 p = p >= np ? p - np : p;
-                const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
-                p = (uint32_t)k < np ? p : np;
+                const uint32_t pa = pbase + ((uint32_t)k < np ? p : np - 1u);
+                p = (uint32_t)k < np ? pbase + p : 4096u;
                 const int32_t j0 = (int32_t)(p * 16u);
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
                 const lds_u8 *sp = lsrow + pa * 8u;
@@ -580,7 +639,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 for (int k = 0; k < F5_NP; ++k) {
                     if (!((redo >> k) & 1u)) continue;
                     uint32_t p = (uint32_t)k + rot;
-                    p = p >= np ? p - np : p;
+                    p = pbase + (p >= np ? p - np : p);
                     const int32_t j0 = (int32_t)(p * 16u) - (int32_t)phi;
                     const bool second = j0 + (int32_t)phi >= qb1;
                     const int32_t sa = second ? a2 : a1, sb_ = second ? b2 : b1;
@@ -591,8 +650,9 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         }
         // ---- hand-over to the general pass: the block's segment of the list -----------------------------------------------
         {
+            if (pair) want_status |= __builtin_amdgcn_update_dpp(0, (int)want_status, 0xB1, 0xF, 0xF, true) != 0;      // (either lane of the read)
             const bool status_only = !general & counted & want_status;        // a base could not be counted: exact status wanted
-            const bool has = general | status_only;
+            const bool has = (general | status_only) & mine;
             const unsigned long long m = __ballot(has);
             if (m) {
                 uint32_t base = 0;
@@ -603,7 +663,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         }
         // ---- next tile ------------------------------------------------------------------------------------------------
         h0 = h1; h1 = h2; g0 = g1; sh0 = sh1;
-        i0 = i1; i1 = i2; i2 = i3; tk0 = tk1; tk1 = tk2; tk2 = tk3;
+        tk0 = tk1; tk1 = tk2; tk2 = tk3; tk3 = tk4;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the loads issued for a tile that does not exist)
     pad_events();
@@ -626,39 +686,31 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     if (tid == 0) { gcnt[blockIdx.x] = s_gcur; if (s_gcur) eb.ctr[29] = (unsigned long long)P.epoch; }      // (every block writes the same value)
 }
 
-struct Fast5Cfg { int waves, qrun; };
-// which build: by the mean padded read length of the batch (bases, a multiple of 8 per read)
-static inline Fast5Cfg fast5_cfg(int64_t n_reads, int64_t n_bases_padded, int window) {
-    const int64_t mean_pad = n_reads > 0 ? (n_bases_padded + n_reads - 1) / n_reads : 0;
-    if (mean_pad <= 152 || window != 4) return Fast5Cfg{8, 9728};          // (the other two are built for the default window only)
-    if (mean_pad <= 192) return Fast5Cfg{6, 13312};
-    return Fast5Cfg{4, 19456};
-}
-static inline FastGrid fast5_grid(int64_t n_reads, int n_cu, const Fast5Cfg &cf) {
+
+static inline FastGrid fast7_grid(int64_t n_reads, int n_cu) {
     int64_t rpb = (n_reads + (int64_t)n_cu - 1) / (int64_t)n_cu;
     rpb = ((rpb + 63) / 64) * 64;
-    if (rpb < 2 * cf.waves * 64) rpb = 2 * cf.waves * 64;
+    if (rpb < 2 * F7_WAVES * 64) rpb = 2 * F7_WAVES * 64;
     return FastGrid{(n_reads + rpb - 1) / rpb, rpb};
 }
 
-static inline int fast5_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out, uint32_t *counts,
-                               const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, const FastGrid &fg, const Fast5Cfg &cf, hipStream_t stream) {
+// clist: 2 * grid * rpb words of scratch (the blocks' bin lists)
+static inline int fast7_launch(const KParams &P, const amp_dev_reads &rd, uint64_t read_base, const DevOut &out, uint32_t *counts,
+                               const EventBuf &eb, uint32_t *glist, uint32_t *gcnt, uint32_t *clist, const FastGrid &fg, hipStream_t stream) {
     const unsigned g = (unsigned)fg.grid;
     const int rpb = (int)fg.rpb;
-#define AMP_F5_GO(w, wv, qr, rp, pw) k_fast5<w, wv, qr, rp, pw><<<g, wv * 64, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb))
-    if (cf.waves == 6) AMP_F5_GO(4, 6, 13312, 2, 512);
-    else if (cf.waves == 4) AMP_F5_GO(4, 4, 19456, 4, 512);
-    else switch (P.window) {
-        case 1: AMP_F5_GO(1, 8, 9728, 4, 256); break;
-        case 2: AMP_F5_GO(2, 8, 9728, 4, 256); break;
-        case 3: AMP_F5_GO(3, 8, 9728, 4, 256); break;
-        case 4: AMP_F5_GO(4, 8, 9728, 4, 256); break;
-        case 5: AMP_F5_GO(5, 8, 9728, 4, 256); break;
-        case 6: AMP_F5_GO(6, 8, 9728, 4, 256); break;
-        case 7: AMP_F5_GO(7, 8, 9728, 4, 256); break;
-        default: AMP_F5_GO(8, 8, 9728, 4, 256); break;
+#define AMP_F7_GO(w) k_fast7<w><<<g, F7_WAVES * 64, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb), 0, clist)
+    switch (P.window) {
+        case 1: AMP_F7_GO(1); break;
+        case 2: AMP_F7_GO(2); break;
+        case 3: AMP_F7_GO(3); break;
+        case 4: AMP_F7_GO(4); break;
+        case 5: AMP_F7_GO(5); break;
+        case 6: AMP_F7_GO(6); break;
+        case 7: AMP_F7_GO(7); break;
+        default: AMP_F7_GO(8); break;
     }
-#undef AMP_F5_GO
+#undef AMP_F7_GO
     return (int)hipGetLastError();
 }
 

@@ -22,6 +22,7 @@
 #include "amp_fast.hpp"
 #include "amp_fast5.hpp"
 #include "amp_fast6.hpp"
+#include "amp_fast7.hpp"
 #include "amp_wave.hpp"
 #include "amp_ins.hpp"
 
@@ -1015,7 +1016,7 @@ int amp_set_params(amp_ctx *c, int32_t min_quality, int32_t window, int32_t do_t
 }
 
 int amp_set_kernel_variant(amp_ctx *c, int variant) {  // 1 = lane-per-read kernels, 2 = fused tile kernel, 3 = split pipeline, 4 / 5 = fast kernel (first / second generation) + general pass
-    if (!c || variant < 0 || variant > 6) return AMP_EINVAL;
+    if (!c || variant < 0 || variant > 7) return AMP_EINVAL;
     c->kernel_variant = variant;
     return AMP_OK;
 }
@@ -1097,7 +1098,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     const int variant = kv >= 5 ? 4 : kv;          // (5 and 6 differ from 4 in the fast kernel only)
     const TileGrid tg = tile_grid(n, c->n_cu);
     const int fast_cus = std::max(1, c->n_cu / c->cu_share);
-    const FastGrid fg = kv == 6 ? fast6_grid(n, fast_cus) : kv == 5 ? fast5_grid(n, fast_cus, f5) : fast_grid(n, fast_cus);
+    const FastGrid fg = kv == 7 ? fast7_grid(n, fast_cus) : kv == 6 ? fast6_grid(n, fast_cus) : kv == 5 ? fast5_grid(n, fast_cus, f5) : fast_grid(n, fast_cus);
     // scratch: [CIGAR ping-pong slots][deferred list][list counts, debug words][variant 3 hand-over][outputs the caller
     // did not ask for but the second pass reads][variant 4: per-block lists, their counts, the dense list, geometry]
     // general pass of variant 4: at most four blocks per CU (its list is usually a tenth of the batch; blocks without
@@ -1109,7 +1110,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // a batch of reads with many CIGAR ops (eight a read on average: Nanopore-like) gets k_long (amp_wave.hpp) for them; the
     // results do not depend on this choice
     const bool long_kernel = variant == 4 && rd->n_cig >= 8 * n;
-    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + 1024 + (long_kernel ? 2 * (size_t)n : 0) + (kv == 6 ? (size_t)fg.grid * (size_t)fg.rpb : 0) : 0;
+    const size_t fast_words = variant == 4 ? (size_t)fg.grid * (size_t)fg.rpb + (size_t)fg.grid * F_WAVES + (size_t)n + 64 + 1024 + (long_kernel ? 2 * (size_t)n : 0) + (kv == 6 ? (size_t)fg.grid * (size_t)fg.rpb : kv == 7 ? 2 * (size_t)fg.grid * (size_t)fg.rpb : 0) : 0;
     HIPCHK(c, c->scratch.ensure((slots * (out.new_cig ? 1 : 2) + (size_t)n * 7 + (size_t)tg.grid * 6 + 64 + dlist_words + fast_words) * 4));
     uint32_t *scr = c->scratch.as<uint32_t>();
     uint32_t *dlist = scr + slots;                                   // one segment of tpb*64 entries per tile-kernel block
@@ -1141,7 +1142,8 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
         if (c->split_timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         uint32_t *segfirst0 = (uint32_t *)geo + 4;
         uint32_t *clist = segfirst0 + 1024 + (long_kernel ? 2 * (size_t)n : 0);      // (variant 6) the blocks' class lists
-        if ((kv == 6 ? fast6_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, clist, fg, c->stream)
+        if ((kv == 7 ? fast7_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, clist, fg, c->stream)
+             : kv == 6 ? fast6_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, clist, fg, c->stream)
              : kv == 5 ? fast5_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, f5, c->stream)
                      : fast_launch(P, *rd, read_base, out, c->d_counts, eb, glist, gcnt, fg, c->stream, dcnt + tg.grid + 64)) != 0) {
             snprintf(c->err, sizeof(c->err), "fast kernel launch failed"); return AMP_EHIP;

@@ -12,7 +12,7 @@ from tests.gpu_util import GpuRunner, assert_same
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[6, 4, 5, 2, 1, 3], ids=["fast_kernel_v6", "fast_kernel", "fast_kernel_v5", "tile_kernel", "lane_kernel", "split_pipeline"])
+@pytest.fixture(scope="module", params=[7, 6, 4, 5, 2, 1, 3], ids=["fast_kernel_v7", "fast_kernel_v6", "fast_kernel", "fast_kernel_v5", "tile_kernel", "lane_kernel", "split_pipeline"])
 def runner(request):
     r = GpuRunner(variant=request.param)
     yield r
@@ -130,7 +130,7 @@ def test_replication_property_full_depth(runner, scheme):
     a = oracle.process(base, g.size, mn, mx, mpl)
     e = runner.engine(g.size)
     e.reset(); e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
-    k = 100 if runner.variant in (4, 5, 6) else 10
+    k = 100 if runner.variant in (4, 5, 6, 7) else 10
     for rep in range(k):
         e.process(base, read_base=0, want_trim=False)
     assert np.array_equal(e.counts(), a.counts * np.uint32(k))
@@ -713,7 +713,7 @@ def test_cu_share_does_not_change_results(runner, scheme):
     """amp_set_cu_share sizes the fast kernel's grid for a part of the chip (callers with several batches in flight run their
     passes side by side): trims, table and events must not depend on it -- plain reads, indel reads handed to the general
     pass and a batch spread thinly over the reference alike."""
-    if runner.variant not in (4, 5, 6):
+    if runner.variant not in (4, 5, 6, 7):
         pytest.skip("only the fast kernels have a grid to size")
     g, pr, amps, mn, mx, mpl = scheme
     batches = [synth.make_amplicon_batch(g, amps, 60000, seed=8),

@@ -14,7 +14,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 g = synth.make_genome(); primers, amps = synth.make_artic_scheme()
 pr = [(s, e) for s, e, _ in primers]
-runners = {v: GpuRunner(variant=v) for v in (1, 2, 3, 4, 5, 6)}
+runners = {v: GpuRunner(variant=v) for v in (1, 2, 3, 4, 5, 6, 7)}
 t0 = time.time(); n_cmp = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
