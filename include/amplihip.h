@@ -249,15 +249,18 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * events of a batch plus 64 slots per wave of the fast kernel (8 per CU) and of the many-op kernel (24 per CU): waves
  * reserve list slots 64 at a time and leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 0 (default) = chosen per batch between 4 and 5 by its mean padded read length (up to 152: 4) and the window (8: 5).  4 = the fast kernel (closed-form trim +
+/* 0 (default) = chosen per batch between 4, 5 and 7 by its mean padded read length (up to 152: 4), the window (8: 5) and its mean number
+ * of CIGAR ops (long reads with three ops a read and more: 7).  4 = the fast kernel (closed-form trim +
  * pileup of reads with one match op or one insertion / deletion of up to 152 bases, every byte loaded once) followed by the
  * general pass over the reads it hands over; 5 = its second generation (reads consumed from LDS staging buffers,
  * branch-free closed forms, reads of up to 304 bases); 6 = its third generation (reads of up to 160 bases sorted into class
- * lists per block, rows gathered by LDS-DMA, three passes from LDS: amp_fast6.hpp; opt-in); 2 = the fused tile kernel over every read; 1 = one-lane-per-read
+ * lists per block, rows gathered by LDS-DMA, three passes from LDS: amp_fast6.hpp; opt-in); 7 = the second generation driven by
+ * per-block lists of reads binned by length (tiles of one length class, two lanes per read of more than 144 bases, reads for the
+ * general pass never in a tile: amp_fast7.hpp; for batches of mixed read lengths); 2 = the fused tile kernel over every read; 1 = one-lane-per-read
  * kernels and 3 = the tile kernel's work cut into three kernels -- 1 to 3 are kept for on-GPU A/B checks (all give
  * identical results).  Runs with window > 8 or min_quality > 128 use variant 2 whatever is set. */
 int amp_set_kernel_variant(amp_ctx *ctx, int variant);
-/* 1 when runs with the ctx's current parameters take a fast kernel (window 1..8, min_quality <= 128, variant 0 / 4 / 5 / 6), 0 when
+/* 1 when runs with the ctx's current parameters take a fast kernel (window 1..8, min_quality <= 128, variant 0 / 4 / 5 / 6 / 7), 0 when
  * every read takes the general tile kernel (same results, about 1.5 x the time); negative on a bad ctx.  Informational: lets a
  * caller that sweeps sliding-window widths know when it has left the fast path (AmpliPy.py:563 takes any width). */
 int amp_fast_path_active(amp_ctx *ctx);
