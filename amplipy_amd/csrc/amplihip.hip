@@ -86,6 +86,7 @@ struct amp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_call = nullptr;
     bool timed = false;
     bool last_split = false;      // the last launch recorded ev1 / ev2
+    int last_kv = 0;              // kernel variant the last batch took (amp_last_kernel_variant)
     bool split_timing = false;    // also time the first kernel of a pass alone (amp_set_timing): costs an idle gap behind it
     int n_cu = 256;
     int cu_share = 1;              // the fast kernels of this ctx are sized for n_cu / cu_share CUs (amp_set_cu_share)
@@ -1027,6 +1028,11 @@ int amp_fast_path_active(amp_ctx *c) {
     return ((kv == 0 || kv >= 4) && c->window <= 8 && c->min_quality <= 128) ? 1 : 0;
 }
 
+int amp_last_kernel_variant(amp_ctx *c) {
+    if (!c) return AMP_EINVAL;
+    return c->last_kv;
+}
+
 int amp_set_cu_share(amp_ctx *c, int divisor) {
     if (!c || divisor < 1 || divisor > 16) return AMP_EINVAL;
     c->cu_share = divisor;
@@ -1197,6 +1203,7 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     HIPCHK(c, hipEventRecord(c->ev3, c->stream));
     c->timed = true;
     c->last_split = variant != 4 || c->split_timing;
+    c->last_kv = kv;
     return AMP_OK;
 }
 

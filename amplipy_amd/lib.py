@@ -27,7 +27,7 @@ EXPORTS = [
     "amp_get_ins_events", "amp_counts_device_ptr", "amp_reduce", "amp_reset", "amp_error_reads",
     "amp_reserve_events", "amp_set_kernel_variant", "amp_set_reference", "amp_call_positions",
     "amp_event_strings", "amp_debug_counters", "amp_call_compact", "amp_debug_blocks", "amp_call_compact_view", "amp_set_timing", "amp_call_compact_begin", "amp_coordinate_helpers", "amp_drain_ins_events", "amp_set_cu_share",
-    "amp_aggregate_ins_events", "amp_fast_path_active",
+    "amp_aggregate_ins_events", "amp_fast_path_active", "amp_last_kernel_variant",
 ]
 
 
@@ -121,6 +121,13 @@ class Engine:
         if rc < 0:
             self._chk(rc, "amp_fast_path_active")
         return rc == 1
+
+    def last_kernel_variant(self):
+        """The kernel variant the last batch took (what the default, 0, resolved to)."""
+        rc = self.L.amp_last_kernel_variant(self.h)
+        if rc < 0:
+            self._chk(rc, "amp_last_kernel_variant")
+        return rc
 
     def set_kernel_variant(self, v):
         self._chk(self.L.amp_set_kernel_variant(self.h, C.c_int(v)), "amp_set_kernel_variant")

@@ -264,6 +264,9 @@ int amp_set_kernel_variant(amp_ctx *ctx, int variant);
  * every read takes the general tile kernel (same results, about 1.5 x the time); negative on a bad ctx.  Informational: lets a
  * caller that sweeps sliding-window widths know when it has left the fast path (AmpliPy.py:563 takes any width). */
 int amp_fast_path_active(amp_ctx *ctx);
+/* The kernel variant the last batch of the ctx took (what 0 = "chosen per batch" resolved to: 4, 5 or 7; 2 for runs outside of the
+ * fast kernels' parameters; 0 before the first batch); negative on a bad ctx.  Informational. */
+int amp_last_kernel_variant(amp_ctx *ctx);
 /* Size the fast kernel's grid for 1 / divisor of the GPU's CUs (1, the default: one block per CU).  For callers that keep
  * several batches in flight on different streams (one ctx each): two passes side by side on half the chip each finish
  * sooner than one after the other on all of it -- a block then works twice as long, so its start-up, its flush and the idle

@@ -977,5 +977,26 @@ def test_fast_path_report(scheme):
     res = e.process(b)
     a = oracle.process(b, g.size, mn, mx, mpl, 20, 12)
     assert np.array_equal(res.new_pos, a.trim.new_pos) and np.array_equal(e.counts(), a.counts)
+    assert e.last_kernel_variant() == 2
     e.set_kernel_variant(2); assert not e.fast_path_active()
+    e.close()
+
+
+def test_the_kernel_is_chosen_by_the_batch(scheme):
+    """amp_last_kernel_variant: 150 bp amplicon reads take the first-generation fast kernel, uniform 250 bp reads the second, a batch
+    of mixed long reads with soft clips and indels everywhere (BASELINE config 5) the list-driven one -- each equal to the oracle."""
+    from amplipy_amd import lib
+    g, pr, amps, mn, mx, mpl = scheme
+    e = lib.Engine(g.size)
+    e.set_primers(mn, mx, mpl); e.set_params(20, 4, True, True)
+    assert e.last_kernel_variant() == 0
+    for b, want in ((synth.make_amplicon_batch(g, amps, 30000, seed=5), 4),
+                    (synth.make_amplicon_batch(g, amps, 20000, seed=6, read_len=250), 5),
+                    (synth.make_config5_batch(g, amps, rep=3, pool_reads=20000, seed=11), 7)):
+        e.reset()
+        res = e.process(b)
+        assert e.last_kernel_variant() == want, (e.last_kernel_variant(), want)
+        a = oracle.process(b, g.size, mn, mx, mpl, 20, 4)
+        assert np.array_equal(res.new_pos, a.trim.new_pos) and np.array_equal(res.new_ncig, a.trim.new_ncig)
+        assert np.array_equal(res.status, a.trim.status) and np.array_equal(e.counts(), a.counts)
     e.close()
