@@ -38,13 +38,13 @@ constexpr int F5_PAD = 16;                // bytes in front of / behind a staged
 // Three builds of the kernel (template parameters WAVES, QRUN, REP; one block per CU, all of its LDS):
 //   8 waves, runs of 9,728 quality bytes (64 reads of up to 152 padded bases: every tile of a 150 bp run fits), packed
 //     windows of 256 positions in 4 replicas
-//   6 waves, runs of 13,312 bytes (64 reads of 208 padded bases on average), windows of 512 positions (a read of 300 bases
-//     does not fit 256) in 2 replicas
-//   4 waves, runs of 19,456 bytes (64 reads of 304 padded bases: every tile of reads the kernel takes fits), 512 positions
-//     in 4 replicas
+//   6 waves, runs of 13,312 bytes (64 reads of 208 padded bases on average), windows of 400 positions (a read of 300 bases
+//     does not fit 256) in 3 replicas
+//   4 waves, runs of 19,456 bytes (64 reads of 304 padded bases: every tile of reads the kernel takes fits), 400 positions
+//     in 5 replicas
 // The host picks by the batch's mean padded read length; reads of a tile that do not fit its run go to the general pass.
-// A counter byte gets at most 64 / REP increments per tile (a read covers a position once): the window is folded every
-// 255 / (64 / REP) tiles at the latest.
+// A counter byte gets at most 4 * ceil(16 / REP) increments per tile (a read covers a position once; lanes go to replicas in
+// groups of four): the window is folded every 255 / that many tiles at the latest.
 // (Four replicas instead of variant 4's eight: two-way bank conflicts cost nothing, the LDS takes four cycles to receive an
 // atomic's operands anyway.)
 
@@ -74,7 +74,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
     const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
-    constexpr int F5_FLUSH = 255 / (64 / F5_REP);
+    constexpr int F5_FLUSH = 255 / (((16 + F5_REP - 1) / F5_REP) * 4);      // (lanes go to replicas in groups of four: so many of them add into one replica at most)
     constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
     __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
     __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
@@ -113,7 +113,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     uint32_t n_err = 0;
     // bank plan: lane l works on piece (k + l) mod np in step k, starts its pieces 8 bases early when bit 1 of l is
     // set and adds into replica (l >> 2) & 3 (replica r is skewed by r banks)
-    const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
+    const uint32_t rep = (F5_REP & (F5_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F5_REP : ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
     const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F5_REPW * 4));
     lds_u8 *const qst = (lds_u8 *)s_q[wave] + F5_PAD;
@@ -646,8 +646,17 @@ static inline int fast5_launch(const KParams &P, const amp_dev_reads &rd, uint64
     const unsigned g = (unsigned)fg.grid;
     const int rpb = (int)fg.rpb;
 #define AMP_F5_GO(w, wv, qr, rp, pw) k_fast5<w, wv, qr, rp, pw><<<g, wv * 64, 0, stream>>>(F_ARGS_PASS(P, rd, out, eb, rpb))
-    if (cf.waves == 6) AMP_F5_GO(4, 6, 13312, 2, 512);
-    else if (cf.waves == 4) AMP_F5_GO(4, 4, 19456, 4, 512);
+    // (replicas / positions of the packed window of the six- and the four-wave build: what the LDS holds.  400 positions take a read of
+    //  304 bases + 16 in front + the spread of a tile's starts; a third / fifth replica instead of positions 400..511 is worth 3 %
+    //  on 176 and 250 bp runs: the counting adds are bound by LDS bank conflicts, see amp_fast7.hpp)
+#ifndef AMP_F5_R6
+#define AMP_F5_R6 3
+#define AMP_F5_P6 400
+#define AMP_F5_R4 5
+#define AMP_F5_P4 400
+#endif
+    if (cf.waves == 6) AMP_F5_GO(4, 6, 13312, AMP_F5_R6, AMP_F5_P6);
+    else if (cf.waves == 4) AMP_F5_GO(4, 4, 19456, AMP_F5_R4, AMP_F5_P4);
     else switch (P.window) {
         case 1: AMP_F5_GO(1, 8, 9728, 4, 256); break;
         case 2: AMP_F5_GO(2, 8, 9728, 4, 256); break;

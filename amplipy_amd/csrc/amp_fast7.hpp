@@ -10,7 +10,7 @@
 // the general list at once.  Tiles are then cut from the lists, longest bin first:
 //   bins 0 and 1: 64 reads, lane = read, 6 / 10 piece slots
 //   bins 2 and 3: 32 reads, TWO lanes per read (lane 2r takes the first 8 / 10 pieces of read r, lane 2r + 1 the others):
-//     the rows of 64 reads of 304 bases do not fit a wave's share of the LDS next to seven other waves, the rows of 32 do,
+//     the rows of 64 reads of 304 bases do not fit a wave's share of the LDS next to six other waves, the rows of 32 do,
 //     and the piece loops are half as long.  Both lanes compute the read's trims (same inputs, same result); the first
 //     failing window is the minimum over the pair; results, indel extras and hand-overs are lane 2r's.
 // A tile's rows are gathered by LDS-DMA into a row-major image with a stride per bin (a multiple of 16 bytes: lane l of
@@ -26,10 +26,44 @@ namespace amp {
 #ifndef AMP_F7_ABL
 #define AMP_F7_ABL 0
 #endif
-constexpr int F7_WAVES = 8;
+// development builds (-DAMP_F7_STAMPS): shader cycles a wave spends in the two waits of a turn, in the piece loops and in all of its
+// turns, summed over the waves into ctr[8 ..], turns into ctr[6] (tools/time_config5.py prints them)
+#ifdef AMP_F7_STAMPS
+#define F7_T(k) do { const unsigned long long f7_n = __builtin_amdgcn_s_memtime(); f7_t[k] += f7_n - f7_prev; f7_prev = f7_n; } while (0)
+#else
+#define F7_T(k) do { } while (0)
+#endif
+#ifndef AMP_F7_LAYOUT
+#define AMP_F7_LAYOUT 0
+#endif
+#ifndef AMP_F7_SKEW
+#define AMP_F7_SKEW 1
+#endif
+#ifndef AMP_F7_REPS
+#define AMP_F7_REPS 4
+#endif
+// Waves per block, replicas and width of a wave's packed window: the LDS holds 8 waves with 2 replicas, 7 with 4 or 6 with 5.  The
+// counting adds are bound by LDS bank conflicts (14.5 LDS cycles per instruction with two replicas, 12 of them conflicts), so
+// replicas buy more than the eighth wave: config 5 takes 1.69 ms with 8 x 2, 1.34 with 7 x 4, 1.43 / 1.42 with 6 x 4 / 6 x 5, 1.52
+// with 5 x 8 (profiles/r04_config5_ablations.txt)
+#ifndef AMP_F7_NWAVES
+#define AMP_F7_NWAVES 7
+#endif
+#ifndef AMP_F7_PWIN
+#define AMP_F7_PWIN 400                   // a read of 304 bases + 16 positions in front + the spread of a tile's starts
+#endif
+#if AMP_F7_LAYOUT == 1                  // (experiment: six waves, reads of up to 208 bases one lane each)
+constexpr int F7_WAVES = 6;
+constexpr int F7_QCAP = 13312;            // 64 x 208, 32 x 304
+constexpr int F7_SCAP = 7168;             // 64 x 112
+constexpr uint32_t F7_B2MAX = 208u, F7_PAIRBIN = 3u, F7_B2MAGIC = 20648882u;
+#else
+constexpr int F7_WAVES = AMP_F7_NWAVES;
 constexpr int F7_QCAP = 9728;             // bytes of a tile's quality image (64 x 144, 32 x 304)
 constexpr int F7_SCAP = 5120;             // ... of its packed-base image (64 x 80, 32 x 160)
-constexpr int F7_REP = 2, F7_PW = 448;    // packed window: positions, replicas (a read of 304 bases + 16 in front + the spread of a tile's starts)
+constexpr uint32_t F7_B2MAX = 224u, F7_PAIRBIN = 2u, F7_B2MAGIC = 19173962u;      // bin 2: reads of up to so many bases; bins from here on hold two lanes per read; ceil(2^32 / F7_B2MAX)
+#endif
+constexpr int F7_REP = AMP_F7_REPS, F7_PW = AMP_F7_PWIN;    // packed window: replicas, positions
 constexpr int F7_NBIN = 4;
 
 // one of four 16-bit / 32-bit constants by a bin number (shifts of packed words: a chain of selects becomes a table in scratch
@@ -52,8 +86,8 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     const amp_dev_reads rd{a_n_reads, a_pos, a_flag, a_tlen, a_lseq, a_cig_off32, a_cig, a_seq_off8, a_seq, a_qual, 0, 0};
     const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
     const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
-    constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
-    constexpr int F5_FLUSH = 255 / (64 / F5_REP);
+    constexpr int F5_REPW = F5_PW + AMP_F7_SKEW;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
+    constexpr int F5_FLUSH = 255 / (((16 + F5_REP - 1) / F5_REP) * 4);      // (lanes go to replicas in groups of four: so many of them add into one replica at most)
     constexpr int F5_QB = F5_PAD + F7_QCAP + 2 * F5_PAD, F5_SB = F5_PAD + F7_SCAP + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the image)
     __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
     __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
@@ -112,7 +146,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
                 const uint32_t nops = c1[r] - c0[r];
                 const bool sf = (wf[r] & 15u) == OP_S, sl = (wl[r] & 15u) == OP_S;
                 const bool cand = ls[r] >= 1u && ls[r] <= (uint32_t)F5_MAXLEN && nops >= 1u && nops <= 5u && (nops < 4u || (nops == 4u ? (sf | sl) : (sf & sl)));
-                const uint32_t cls = !valid ? 5u : !cand ? 4u : ls[r] <= 80u ? 0u : ls[r] <= 144u ? 1u : ls[r] <= 224u ? 2u : 3u;
+                const uint32_t cls = !valid ? 5u : !cand ? 4u : ls[r] <= 80u ? 0u : ls[r] <= 144u ? 1u : ls[r] <= F7_B2MAX ? 2u : 3u;
 #pragma unroll
                 for (uint32_t c = 0; c < 5u; ++c) {
                     const unsigned long long m = __ballot(cls == c);
@@ -132,7 +166,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     __syncthreads();
     // tiles, longest bin first: tiles [0, t3) of bin 3, [t3, t2) of bin 2 (32 reads each), [t2, t1) of bin 1, [t1, n_tb) of bin 0
     const uint32_t nb0 = s_nb[0], nb1 = s_nb[1], nb2 = s_nb[2], nb3 = s_nb[3];
-    const uint32_t t3 = (nb3 + 31u) >> 5, t2 = t3 + ((nb2 + 31u) >> 5), t1 = t2 + ((nb1 + 63u) >> 6), n_tb = (AMP_F7_ABL & 4) ? 0u : t1 + ((nb0 + 63u) >> 6);
+    const uint32_t t3 = (nb3 + 31u) >> 5, t2 = t3 + (F7_PAIRBIN <= 2u ? (nb2 + 31u) >> 5 : (nb2 + 63u) >> 6), t1 = t2 + ((nb1 + 63u) >> 6), n_tb = (AMP_F7_ABL & 4) ? 0u : t1 + ((nb0 + 63u) >> 6);
     auto take_ticket = [&]() {
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add((lds_u32 *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -141,7 +175,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     uint32_t n_err = 0;
     // bank plan: lane l works on piece (k + l) mod np in step k, starts its pieces 8 bases early when bit 1 of l is
     // set and adds into replica (l >> 2) & 3 (replica r is skewed by r banks)
-    const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
+    const uint32_t rep = (F5_REP & (F5_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F5_REP : ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
     const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F5_REPW * 4));
     lds_u8 *const qst = (lds_u8 *)s_q[wave] + F5_PAD;
@@ -200,7 +234,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         const uint32_t b = bin_of(tk);
         const uint32_t first = f7_pick32(b, t1, t2, t3, 0u), cnt = f7_pick32(b, nb0, nb1, nb2, nb3);      // (by value: a select between captured variables is a select between their addresses, and puts them in scratch memory)
         const uint32_t ln = f7_lane();
-        const uint32_t j = b >= 2u ? (tk - first) * 32u + (ln >> 1) : (tk - first) * 64u + ln;
+        const uint32_t j = b >= F7_PAIRBIN ? (tk - first) * 32u + (ln >> 1) : (tk - first) * 64u + ln;
         const bool valid = tk < n_tb && j < cnt;
         const uint32_t at = (b >> 1) * (uint32_t)reads_per_block + ((b & 1u) ? (uint32_t)reads_per_block - 1u - j : j);
         const uint32_t e = seg[valid ? at : 0u];
@@ -236,8 +270,8 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     auto geometry = [&](const HdrP &h, uint32_t tk) {
         Geo g;
         g.bin = bin_of(tk);
-        const bool pair = g.bin >= 2u;
-        const uint32_t qs = f7_pick16(g.bin, 80u, 144u, 224u, 304u);
+        const bool pair = g.bin >= F7_PAIRBIN;
+        const uint32_t qs = f7_pick16(g.bin, 80u, 144u, F7_B2MAX, 304u);
         const uint32_t ss = f7_pick16(g.bin, 48u, 80u, 112u, 160u);
         const uint32_t na = 8u + (g.bin & 1u) * 2u;                 // pieces of a pair's first lane (bin 2: 8, bin 3: 10)
         const uint32_t r = pair ? (uint32_t)lane >> 1 : (uint32_t)lane;
@@ -271,10 +305,10 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     // bases (8: qualities, 4: packed bases).  Bytes of a row behind the end of the batch's buffer are fetched from its end
     // (16 bytes of slack); they lie behind the read's own bytes.
     auto issue_rows = [&](const uint8_t *base, uint32_t unit, const HdrP &h, uint32_t bin, bool bases, lds_u8 *stage) {
-        const bool pair = bin >= 2u;
-        const uint32_t stride = bases ? f7_pick16(bin, 48u, 80u, 112u, 160u) : f7_pick16(bin, 80u, 144u, 224u, 304u);
+        const bool pair = bin >= F7_PAIRBIN;
+        const uint32_t stride = bases ? f7_pick16(bin, 48u, 80u, 112u, 160u) : f7_pick16(bin, 80u, 144u, F7_B2MAX, 304u);
         const uint32_t magic = bases ? f7_pick32(bin, 89478486u, 53687092u, 38347923u, 26843546u)
-                                     : f7_pick32(bin, 53687092u, 29826162u, 19173962u, 14128182u);      // ceil(2^32 / stride)
+                                     : f7_pick32(bin, 53687092u, 29826162u, F7_B2MAGIC, 14128182u);      // ceil(2^32 / stride)
         const uint32_t ln16 = f7_lane() * 16u;
         const uint32_t nbytes = (pair ? 32u : 64u) * stride;
         const int ninst = (AMP_F7_ABL & 2) ? 0 : (int)((nbytes + 1023u) >> 10);
@@ -316,10 +350,16 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
     }
     Tabs tb0 = load_tabs(h0, sh0);
     uint32_t pfA = 0u, pfB = 0u;                   // (L2 prefetch of the next tile's bases: see below)
+#ifdef AMP_F7_STAMPS
+    unsigned long long f7_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f7_prev = __builtin_amdgcn_s_memtime();
+    uint32_t f7_turns = 0;
+#endif
     while (tk0 < n_tb) {
         // ---- everything issued a phase or more ago has arrived: this tile's qualities and table entries, the next tile's
         // CIGAR words, the header of the tile behind it -------------------------------------------------------------------
+        F7_T(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        F7_T(1);
         asm volatile("" : : "v"(pfA), "v"(pfB));
         // (every register a load of the last turn -- or of the prologue -- wrote is touched HERE, where nothing is in flight: left to its
         // own devices the compiler waits at the first use, behind the issue of this tile's bases, and the wave sits out their latency)
@@ -335,7 +375,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         // this tile's packed bases start moving (their buffer was in use until the end of the last tile)
         issue_rows(rd.seq, 4u, h, g.bin, true, sst);
         const int64_t i = (int64_t)h.idx;
-        const bool pair = g.bin >= 2u, mine = !g.half;                // (pair: uniform; mine: the lane that stores the read's results)
+        const bool pair = g.bin >= F7_PAIRBIN, mine = !g.half;                // (pair: uniform; mine: the lane that stores the read's results)
         const int32_t pos = h.pos;
         const uint32_t lseq = h.lseq(), flag = h.flag(), c0 = h.c0, o8 = h.o8;
         const uint32_t np = g.np, phi = g.fastq ? phi_lane : 0u;
@@ -376,6 +416,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         // bits (bit b: the W-byte window starting at base b of the piece sums to less than W * min_quality), of which the
         // first / last inside [lo, hi - W] give the first failing window start (forward) / last failing window end
         // (reverse); and 16 good-quality bits, kept as ok[k] for the counting phase ------------------------------------------
+        F7_T(4);
         const uint32_t rot = ((uint32_t)lane >> (pair ? 1 : 0)) % np;
         const uint32_t pbase = g.pbase;
         const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
@@ -407,6 +448,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
             const int32_t fo_ = __builtin_amdgcn_update_dpp(0, ffmin, 0xB1, 0xF, 0xF, true), lo_ = __builtin_amdgcn_update_dpp(0, lemax, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
             ffmin = fo_ < ffmin ? fo_ : ffmin; lemax = lo_ > lemax ? lo_ : lemax;
         }
+        F7_T(5);
         const uint32_t fb = lq[0];                                             // 0xFF = QUAL '*'
         // ---- quality clip (A:589-686) --------------------------------------------------------------------------------
         int32_t iq = rev ? 0 : qlen;
@@ -455,7 +497,9 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
             okB = ok_bits16(make_uint4(a.x, a.y, b.x, b.y), mqb);
         }
         // ---- the tile's bases have arrived; the quality buffer is free: results out, the next tile's loads go out ------
+        F7_T(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        F7_T(3);
         {
             // [S a][op m1][I|D k][op m2][S c], absent parts left out
             const uint32_t part[5] = {((uint32_t)s.a << 4) | OP_S, ((uint32_t)s.m1 << 4) | s.op, ((uint32_t)s.k << 4) | (s.kind == 1 ? OP_I : OP_D),
@@ -569,6 +613,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
                 ev_base += total; ev_left -= total;
             }
         }
+        F7_T(6);
         uint32_t redo = 0;                        // pieces (slots) the careful loop has to do; bit F5_NP = group B
         // group B: the part of the second segment that shares a piece with the first
         const int32_t jstar = (qb1 - 1) & ~15;                       // the piece that holds the first segment's last base
@@ -617,6 +662,7 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
             }
             todo = todo & !now;
         }
+        F7_T(7);
         bool want_status = bad_extra;
         if (__ballot(redo != 0u)) {
             // careful loop (rare): bases of the flagged pieces one by one, straight from memory into the 32-bit counters
@@ -664,8 +710,14 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         // ---- next tile ------------------------------------------------------------------------------------------------
         h0 = h1; h1 = h2; g0 = g1; sh0 = sh1;
         tk0 = tk1; tk1 = tk2; tk2 = tk3; tk3 = tk4;
+#ifdef AMP_F7_STAMPS
+        ++f7_turns;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the loads issued for a tile that does not exist)
+#ifdef AMP_F7_STAMPS
+    if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&ctr[8 + k], f7_t[k]); atomicAdd(&ctr[6], (unsigned long long)f7_turns); }
+#endif
     pad_events();
     if (pw_tiles && n_tb) fold();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

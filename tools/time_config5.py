@@ -26,6 +26,17 @@ for it in range(3):
     dc = e.debug_counters()
     print("launch %d: all kernels %.3f ms (fast kernel %.3f) = %.3f ms per 1 M reads -> %.1f M reads/s, %.1f G bases/s; general-pass reads %d, of which %d left to the second pass"
           % (it, tot, scan, tot / (b.n / 1e6), b.n / tot / 1e3, b.total_bases() / tot / 1e6, int(dc[7]), int(dc[3])))
+if os.environ.get("AMP_F7_STAMPS"):
+    dc = e.debug_counters(); turns = max(int(dc[6]), 1)
+    names = ["count pass tail + hand-over (to the top of the next turn)", "WAIT at the top", "next tile's shapes, bases issued, window, primer clips", "WAIT in the middle",
+             "", "quality pass", "quality clip, extras' qualities", "count pass"]
+    # stamps: 0 top-before-wait, 1 after, 4 before quality pass, 5 after, 2 before mid wait, 3 after, 6 before count pass, 7 after
+    order = [1, 4, 5, 2, 3, 6, 7, 0]
+    label = {1: "WAIT at the top of the turn", 4: "shapes of the next tile, bases issued, window, primer clips", 5: "quality pass (piece loop)", 2: "quality clip, qualities of the extras",
+             3: "WAIT in the middle (the tile's bases)", 6: "results, next tile's requests, pad patch, indel extras", 7: "count pass (piece loop)", 0: "careful loop, hand-over, renames"}
+    tot = float(sum(int(dc[8 + k]) for k in range(8)))
+    print("k_fast7 stamps (last launch): %d turns, %.0f shader cycles per turn" % (turns, tot / turns))
+    for k in order: print("   %-62s %8.0f  %5.1f %%" % (label[k], int(dc[8 + k]) / turns, 100.0 * int(dc[8 + k]) / tot))
 if "--no-check" not in sys.argv:
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
