@@ -56,7 +56,10 @@ __device__ __forceinline__ Cig2 cig2_of(const Bf &b) { return Cig2{b.op, b.a, b.
 constexpr int F_NP = 10;              // 16-base pieces per read held in registers
 constexpr int F_MAXLEN = 152;         // longest read the fast path takes: F_NP pieces must cover it from 8 bases before its start
 constexpr int F_PW = 256;             // reference positions covered by a wave's packed window
-constexpr int F_REP = 8;              // replicas of the packed window
+#ifndef AMP_F_REPS
+#define AMP_F_REPS 8
+#endif
+constexpr int F_REP = AMP_F_REPS;     // replicas of the packed window
 constexpr int F_REPW = F_PW + 1;      // words per replica: one word of skew, so that replica r is shifted by r banks
 #ifndef AMP_F_BW
 #define AMP_F_BW 512
@@ -414,7 +417,7 @@ k_fast(F_ARGS F_DBG_PARAM) {
     const int64_t wend = re;                                        // (a tile's lanes past the block's reads are idle)
     unsigned long long n_err = 0;
     // lane constants of the bank plan (see the head of this file)
-    const uint32_t rep = ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
+    const uint32_t rep = (F_REP & (F_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F_REP : ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
     lds_u8 *const wrep = (lds_u8 *)pwin + rep * (uint32_t)(F_REPW * 4);
     lds_u8 *const stage = (lds_u8 *)s_stage[wave] + F_PAD;          // the run starts here

@@ -46,8 +46,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-SCAN_KERNELS = {0: "scan pass: k_fast (k_fast5 for reads of more than 152 bases) + k_tile<LIST> + k_deferred_heavy",
+SCAN_KERNELS = {0: "scan pass: k_fast (k_fast5 for reads of more than 152 bases, k_fast7 for long reads with three CIGAR ops a read and more) + k_tile<LIST> + k_deferred_heavy",
                 4: "scan pass: k_fast + k_tile<LIST> + k_deferred_heavy", 5: "scan pass: k_fast5 + k_tile<LIST> + k_deferred_heavy",
+                6: "scan pass: k_fast6 + k_tile<LIST> + k_deferred_heavy", 7: "scan pass: k_fast7 + k_tile<LIST> + k_deferred_heavy",
                 2: "scan pass: k_tile + k_deferred_heavy",
                 3: "scan pass: k_trim + k_scan + k_tile<SPLIT> + k_deferred_heavy", 1: "k_reads_lane"}
 
