@@ -333,6 +333,8 @@ def run_amplipy(untrimmed_reads_fn=None, primer_fn=None, reference_fn=None, trim
         ref_id, ref_seq = load_ref_genome(reference_fn)
     G = len(ref_seq)
     eng = lib.Engine(G, device=device)
+    if os.environ.get("AMPLIPY_DEV") == "1" and os.environ.get("AMPLIPY_KERNEL_VARIANT"):      # (A/B checks of the tests: all variants give the same files)
+        eng.set_kernel_variant(int(os.environ["AMPLIPY_KERNEL_VARIANT"]))
     table = None
     final_trimmed_fn = None
     if dist is not None:

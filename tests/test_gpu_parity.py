@@ -982,6 +982,37 @@ def test_fast_path_report(scheme):
     e.close()
 
 
+def test_cli_on_mixed_long_reads_matches_the_general_kernel(tmp_path, scheme, monkeypatch):
+    """`aio` on a BAM of mixed 75-300 bp reads with soft clips and indels everywhere (BASELINE config 5 in small), walked in pieces: the
+    default choice (the list-driven fast kernel for such batches) writes the files the general tile kernel writes."""
+    from amplipy_amd import amplipy, bam_native, synth as sy
+    g, pr, amps, mn, mx, mpl = scheme
+    b = sy.make_config5_batch(g, amps, rep=2, pool_reads=30000, seed=17)
+    ref = tmp_path / "ref.fas"; ref.write_text(">SYN_REF\n" + sy.genome_string(g) + "\n")
+    bed = tmp_path / "p.bed"; bed.write_text("".join("SYN_REF\t%d\t%d\tp%d\n" % (s, e, i) for i, (s, e) in enumerate(pr)))
+    from tools.e2e_legs import write_bam
+    seed = str(tmp_path / "seed.bam"); write_bam(seed, b.slice(0, 8), g.size)
+    inp = str(tmp_path / "in.bam")
+    sf = bam_native.BamFile(seed)
+    w = bam_native.BamWriter(inp, sf.header_text, sf, level=1); w.write_batch(b); w.close(); sf.close()
+    monkeypatch.setenv("AMPLIPY_PART_BYTES", str(1 << 20))
+    outs = {}
+    for tag, var in (("default", None), ("general", "2")):
+        monkeypatch.setenv("AMPLIPY_DEV", "1")
+        if var: monkeypatch.setenv("AMPLIPY_KERNEL_VARIANT", var)
+        else: monkeypatch.delenv("AMPLIPY_KERNEL_VARIANT", raising=False)
+        o = {k: str(tmp_path / ("%s.%s" % (tag, ext))) for k, ext in (("t", "bam"), ("v", "vcf"), ("c", "fas"))}
+        amplipy.main(["aio", "-i", inp, "-p", str(bed), "-r", str(ref), "-ot", o["t"], "-ov", o["v"], "-oc", o["c"]])
+        outs[tag] = o
+    assert open(outs["default"]["v"]).read() == open(outs["general"]["v"]).read()
+    assert open(outs["default"]["c"]).read() == open(outs["general"]["c"]).read()
+    a, c = bam_native.BamFile(outs["default"]["t"]), bam_native.BamFile(outs["general"]["t"])
+    assert a.n_records == c.n_records and a.n_records > 20000      # (AmpliPy.py:910: the reads a primer or quality clip touched)
+    ba, _ = a.decode(0, a.n_records, copy=True); bc, _ = c.decode(0, c.n_records, copy=True)
+    assert np.array_equal(ba.pos, bc.pos) and np.array_equal(ba.cig, bc.cig) and np.array_equal(ba.cig_off, bc.cig_off)
+    a.close(); c.close()
+
+
 def test_the_kernel_is_chosen_by_the_batch(scheme):
     """amp_last_kernel_variant: 150 bp amplicon reads take the first-generation fast kernel, uniform 250 bp reads the second, a batch
     of mixed long reads with soft clips and indels everywhere (BASELINE config 5) the list-driven one -- each equal to the oracle."""
