@@ -213,14 +213,14 @@ def make_mixed_segments(genome, amps, n_reads, seed):
     return segs
 
 
-def random_segments(rng, n, ref_len, primers, weird=0.15, domain_errors=True):
+def random_segments(rng, n, ref_len, primers, weird=0.15, domain_errors=True, max_len=160):
     """Adversarial reads for parity tests: every CIGAR op, clips, indels at the edges,
     low-quality runs, reads inside primers, and (optionally) inputs on which the reference
     raises."""
     segs = []
     primers = list(primers)
     for _ in range(n):
-        L = int(rng.integers(12, 161))
+        L = int(rng.integers(12, max_len + 1))
         is_weird = rng.random() < weird
         ops = []
         q_left = L

@@ -20,9 +20,11 @@ for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     mq = int(rng.choice([0, 2, 13, 20, 30, 41])); w = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 30])); off = int(rng.integers(0, 8))
     mn, mx, mpl = oracle.find_overlapping_primers(g.size, pr, off)
-    kind = seed % 3
+    kind = seed % 4
     if kind == 0:
         segs = synth.random_segments(rng, 5000, g.size, pr)
+    elif kind == 3:
+        segs = synth.random_segments(rng, 5000, g.size, pr, max_len=304)        # (the length bins and lane pairs of the list-driven fast kernel)
     elif kind == 1:
         segs = synth.make_mixed_segments(g, amps, 5000, seed=seed)
     else:
