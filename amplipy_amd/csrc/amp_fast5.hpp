@@ -542,19 +542,32 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
                 redo |= count_piece5(sq, mB, dbase2 + jb, lim16, wrep) << F5_NP;
             }
+            // The packed bases of FIVE pieces are read before their adds: LDS operations of a wave complete in order, so a read behind
+            // the sixteen adds of a piece waits for every one of them (the compiler cannot see the adds and waits with lgkmcnt(0)); read
+            // piece by piece the loop drained the LDS queue once per slot (amp_fast7.hpp, whose lanes have ten pieces at most, reads all)
 #pragma unroll
-            for (int k = 0; k < F5_NP; ++k) {
-                if (!((live >> k) & 1u) || (AMP_F5_ABL & 2)) continue;
-                uint32_t p = (uint32_t)k + rot;
-                p = p >= np ? p - np : p;
-                const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
-                p = (uint32_t)k < np ? p : np;
-                const int32_t j0 = (int32_t)(p * 16u);
-                const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
-                const lds_u8 *sp = lsrow + pa * 8u;
-                const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
-                const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
-                redo |= count_piece5(sq, fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
+            for (int c = 0; c < F5_NP; c += 5) {
+                if (!((live >> c) & 1u) || (AMP_F5_ABL & 2)) continue;      // (uniform; the live slots are the low ones)
+                uint2 sqv[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    uint32_t p = (uint32_t)(c + j) + rot;
+                    p = p >= np ? p - np : p;
+                    const lds_u8 *sp = lsrow + ((uint32_t)(c + j) < np ? p : np - 1u) * 8u;
+                    sqv[j] = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int k = c + j;
+                    if (!((live >> k) & 1u)) continue;
+                    uint32_t p = (uint32_t)k + rot;
+                    p = p >= np ? p - np : p;
+                    p = (uint32_t)k < np ? p : np;
+                    const int32_t j0 = (int32_t)(p * 16u);
+                    const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
+                    const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
+                    redo |= count_piece5(sqv[j], fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
+                }
             }
             todo = todo & !now;
         }

@@ -65,6 +65,7 @@ constexpr uint32_t F7_B2MAX = 224u, F7_PAIRBIN = 2u, F7_B2MAGIC = 19173962u;    
 #endif
 constexpr int F7_REP = AMP_F7_REPS, F7_PW = AMP_F7_PWIN;    // packed window: replicas, positions
 constexpr int F7_NBIN = 4;
+constexpr int F7_SLOTS = AMP_F7_LAYOUT == 1 ? 14 : 10;      // pieces of a LANE at most (a read of more than 144 bases has two lanes)
 
 // one of four 16-bit / 32-bit constants by a bin number (shifts of packed words: a chain of selects becomes a table in scratch
 // memory, and every load from it makes the wave wait for all of its loads in flight)
@@ -312,12 +313,23 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         const uint32_t ln16 = f7_lane() * 16u;
         const uint32_t nbytes = (pair ? 32u : 64u) * stride;
         const int ninst = (AMP_F7_ABL & 2) ? 0 : (int)((nbytes + 1023u) >> 10);
-        for (int sl = 0; sl < ninst; ++sl) {
+        // the rows' addresses of ALL instructions first (one wait for the ten permutes instead of one each), then the instructions
+        constexpr int MAXI = (F7_QCAP + 1023) / 1024;
+        uint32_t o8v[MAXI], wv[MAXI];
+#pragma unroll
+        for (int sl = 0; sl < MAXI; ++sl) {
+            if (bases && sl >= (F7_SCAP + 1023) / 1024) break;       // (`bases` is a constant at both call sites)
             const uint32_t off0 = (uint32_t)(sl * 1024) + ln16, off = off0 < nbytes ? off0 : nbytes - 16u;
-            const uint32_t row = __umulhi(off, magic), within = off - row * stride;
-            const uint32_t o8 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pair ? row * 2u : row) * 4u), (int)h.o8);      // (all lanes take part: a lane that is switched off hands out nothing)
-            const uint32_t lim = (q_tot8 - o8) * unit;
-            if (off0 < nbytes) dma16(base + (int64_t)o8 * unit + (within < lim ? within : lim), stage + sl * 1024);      // (lanes past the image: the staging buffer ends there)
+            const uint32_t row = __umulhi(off, magic);
+            wv[sl] = off - row * stride;
+            o8v[sl] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pair ? row * 2u : row) * 4u), (int)h.o8);      // (all lanes take part: a lane that is switched off hands out nothing)
+        }
+#pragma unroll
+        for (int sl = 0; sl < MAXI; ++sl) {
+            if (sl >= ninst || (bases && sl >= (F7_SCAP + 1023) / 1024)) break;      // (uniform)
+            const uint32_t off0 = (uint32_t)(sl * 1024) + ln16;
+            const uint32_t lim = (q_tot8 - o8v[sl]) * unit;
+            if (off0 < nbytes) dma16(base + (int64_t)o8v[sl] * unit + (wv[sl] < lim ? wv[sl] : lim), stage + sl * 1024);      // (lanes past the image: the staging buffer ends there)
         }
     };
 
@@ -422,18 +434,26 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         const uint32_t live = wave_or_u32((1u << np) - 1u);                    // bit k: some lane of the tile has a piece in slot k
         const int32_t lrow = (int32_t)g.row - (int32_t)phi;                    // >= -8: the pad in front of the run
         const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
-        uint32_t fo[F5_NP];
+        uint32_t fo[F7_SLOTS];
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
-#pragma unroll
-        for (int k = 0; k < F5_NP; ++k) {
-            fo[k] = 0u;
-            if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;             // (uniform)
+        // (the 24 bytes of slot k + 1 are asked for before slot k is worked on: a slot's LDS round trip lies under its predecessor's work)
+        auto piece_bytes = [&](int k, amp_u32x2 &a, amp_u32x2 &b, amp_u32x2 &c) {
             uint32_t p = (uint32_t)k + rot;
             p = p >= np ? p - np : p;
-            const uint32_t pa = pbase + ((uint32_t)k < np ? p : np - 1u);
+            const lds_u8 *src = qst + lrow + (int32_t)((pbase + ((uint32_t)k < np ? p : np - 1u)) * 16u);
+            a = *(const lds_u32x2 *)src; b = *(const lds_u32x2 *)(src + 8); c = *(const lds_u32x2 *)(src + 16);
+        };
+        amp_u32x2 an, bn, cn;
+        piece_bytes(0, an, bn, cn);
+#pragma unroll
+        for (int k = 0; k < F7_SLOTS; ++k) {
+            fo[k] = 0u;
+            if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;             // (uniform)
+            const amp_u32x2 a = an, b = bn, c = cn;
+            if (k + 1 < F7_SLOTS) piece_bytes(k + 1, an, bn, cn);
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
             p = (uint32_t)k < np ? pbase + p : 4096u;                          // (a slot the lane has no piece for: outside every range)
-            const lds_u8 *src = qst + lrow + (int32_t)(pa * 16u);
-            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
             const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
             fo[k] = ok_bits16(q, mqb);
             if (P.do_trim) {
@@ -624,6 +644,17 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
         // step from one pile of reads to the next) is counted in PASSES: fold, re-anchor at the first lane left.
         const int32_t end_pos = two ? pos2 + s.m2 : tpos + s.m1;                   // one past the last counted position
         const lds_u8 *const lsrow = sst + (int32_t)g.srow - (int32_t)(phi >> 1);
+        // The packed bases of all of the lane's pieces are read BEFORE the first add: LDS operations of a wave complete in order, so a read
+        // behind the sixteen adds of a piece waits for every one of them (the compiler cannot see the adds and waits with lgkmcnt(0)):
+        // read piece by piece, the counting loop drained the LDS queue once per slot.
+        uint2 sqv[F7_SLOTS];
+#pragma unroll
+        for (int k = 0; k < F7_SLOTS; ++k) {
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
+            const lds_u8 *sp = lsrow + (pbase + ((uint32_t)k < np ? p : np - 1u)) * 8u;
+            sqv[k] = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+        }
         bool todo = counted;
         for (bool first_pass = true;; first_pass = false) {
             const unsigned long long tm = __ballot(todo);
@@ -647,16 +678,14 @@ k_fast7(F_ARGS, int32_t pad19, uint32_t *clist) {      // (individual arguments,
                 redo |= count_piece5(sq, mB, dbase2 + jb, lim16, wrep) << F5_NP;
             }
 #pragma unroll
-            for (int k = 0; k < F5_NP; ++k) {
+            for (int k = 0; k < F7_SLOTS; ++k) {
                 if (!((live >> k) & 1u) || (AMP_F5_ABL & 2)) continue;
                 uint32_t p = (uint32_t)k + rot;
                 p = p >= np ? p - np : p;
-                const uint32_t pa = pbase + ((uint32_t)k < np ? p : np - 1u);
                 p = (uint32_t)k < np ? pbase + p : 4096u;
                 const int32_t j0 = (int32_t)(p * 16u);
                 const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
-                const lds_u8 *sp = lsrow + pa * 8u;
-                const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
+                const uint2 sq = sqv[k];
                 const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
                 redo |= count_piece5(sq, fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
             }
