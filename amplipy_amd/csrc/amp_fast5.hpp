@@ -330,16 +330,24 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
         const lds_u8 *const lq = qst + g.row;                                  // the read's qualities in the staging buffer
         uint32_t fo[F5_NP];
         int32_t ffmin = 0x7FFFFFFF, lemax = -1;
+        // (the 24 bytes of slot k + 1 are asked for before slot k is worked on: a slot's LDS round trip lies under its predecessor's work)
+        auto piece_bytes = [&](int k, amp_u32x2 &a, amp_u32x2 &b, amp_u32x2 &c) {
+            uint32_t p = (uint32_t)k + rot;
+            p = p >= np ? p - np : p;
+            const lds_u8 *src = qst + lrow + (int32_t)(((uint32_t)k < np ? p : np - 1u) * 16u);
+            a = *(const lds_u32x2 *)src; b = *(const lds_u32x2 *)(src + 8); c = *(const lds_u32x2 *)(src + 16);
+        };
+        amp_u32x2 an, bn, cn;
+        piece_bytes(0, an, bn, cn);
 #pragma unroll
         for (int k = 0; k < F5_NP; ++k) {
             fo[k] = 0u;
             if (!((live >> k) & 1u) || (AMP_F5_ABL & 1)) continue;             // (uniform)
+            const amp_u32x2 a = an, b = bn, c = cn;
+            if (k + 1 < F5_NP) piece_bytes(k + 1, an, bn, cn);
             uint32_t p = (uint32_t)k + rot;
             p = p >= np ? p - np : p;
-            const uint32_t pa = (uint32_t)k < np ? p : np - 1u;
             p = (uint32_t)k < np ? p : np;
-            const lds_u8 *src = qst + lrow + (int32_t)(pa * 16u);
-            const amp_u32x2 a = *(const lds_u32x2 *)src, b = *(const lds_u32x2 *)(src + 8), c = *(const lds_u32x2 *)(src + 16);
             const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
             fo[k] = ok_bits16(q, mqb);
             if (P.do_trim) {
