@@ -60,6 +60,9 @@ constexpr int F_PW = 256;             // reference positions covered by a wave's
 #define AMP_F_REPS 8
 #endif
 constexpr int F_REP = AMP_F_REPS;     // replicas of the packed window
+#ifndef AMP_F_ADD64
+#define AMP_F_ADD64 1                 // 1: eight 64-bit adds per piece into even / odd arrays (count_piece5q), F_REP / 2 replicas of two arrays each; 0: sixteen 32-bit adds
+#endif
 constexpr int F_REPW = F_PW + 1;      // words per replica: one word of skew, so that replica r is shifted by r banks
 #ifndef AMP_F_BW
 #define AMP_F_BW 512
@@ -310,6 +313,38 @@ __device__ __forceinline__ uint32_t count_piece5(const uint2 &sq, uint32_t m16, 
 #undef F_AD
     return redo ? 1u : 0u;
 }
+// The same with EIGHT 64-bit adds instead of sixteen 32-bit ones: an LDS atomic is issued per wave-instruction whatever its width,
+// and the counting phase is bound by how fast a SIMD gets its atomics into the LDS (sixteen cycles apiece when the four SIMDs of a
+// CU share the pipe fairly), not by its vector instructions.  ds_add_u64 faults on an address that is not a multiple of 8, and
+// whether a piece starts on an even or an odd window offset depends on the read: a replica therefore holds TWO arrays, the second
+// ooff bytes behind the first with ooff = 4 (mod 8) (an odd number of words per array), and a piece with an odd offset adds into the
+// second one, where ITS pairs are aligned.  The two halves of a pair come from two SDWA shifts into the FIXED registers v[252:253] / v[254:255] (an asm operand
+// cannot name the halves of a 64-bit register).  Counter bytes never carry (flush discipline), so the low word cannot spill over.
+__device__ __forceinline__ uint32_t count_piece5q(const uint2 &sq, uint32_t m16, int32_t d0, int32_t lim16, uint32_t wrep, uint32_t ooff) {
+    const bool inwin = (d0 >= 0) & (d0 <= lim16);
+    const bool redo = (m16 != 0u) & (!inwin | (nibbles_bad(sq.x, sq.y) != 0u));
+    const uint32_t m = redo ? 0u : m16;
+    const uint32_t se0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.x >> 4) & 0x07070707u);
+    const uint32_t so0 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.x & 0x07070707u);
+    const uint32_t se1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, (sq.y >> 4) & 0x07070707u);
+    const uint32_t so1 = __builtin_amdgcn_perm(0x00000010u, 0x00080018u, sq.y & 0x07070707u);
+    const uint32_t f0 = nibble_to_bytes(m, 0), f1 = nibble_to_bytes(m, 1), f2 = nibble_to_bytes(m, 2), f3 = nibble_to_bytes(m, 3);
+    const uint32_t wb = wrep + (inwin ? (uint32_t)d0 * 4u + (((uint32_t)d0 & 1u) ? ooff : 0u) : 0u);
+#define F_SH(d, sh, js, v, jv) "v_lshlrev_b32_sdwa " d ", " sh ", " v " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_" #js " src1_sel:BYTE_" #jv "\n\t"
+#define F_AQ(t, off) "ds_add_u64 %0, " t " offset:" #off "\n\t"
+    asm volatile(F_SH("v252", "%1", 0, "%5", 0) F_SH("v253", "%2", 0, "%5", 1) F_AQ("v[252:253]", 0)
+                 F_SH("v254", "%1", 1, "%5", 2) F_SH("v255", "%2", 1, "%5", 3) F_AQ("v[254:255]", 8)
+                 F_SH("v252", "%1", 2, "%6", 0) F_SH("v253", "%2", 2, "%6", 1) F_AQ("v[252:253]", 16)
+                 F_SH("v254", "%1", 3, "%6", 2) F_SH("v255", "%2", 3, "%6", 3) F_AQ("v[254:255]", 24)
+                 F_SH("v252", "%3", 0, "%7", 0) F_SH("v253", "%4", 0, "%7", 1) F_AQ("v[252:253]", 32)
+                 F_SH("v254", "%3", 1, "%7", 2) F_SH("v255", "%4", 1, "%7", 3) F_AQ("v[254:255]", 40)
+                 F_SH("v252", "%3", 2, "%8", 0) F_SH("v253", "%4", 2, "%8", 1) F_AQ("v[252:253]", 48)
+                 F_SH("v254", "%3", 3, "%8", 2) F_SH("v255", "%4", 3, "%8", 3) "ds_add_u64 %0, v[254:255] offset:56"
+                 : : "v"(wb), "v"(se0), "v"(so0), "v"(se1), "v"(so1), "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "memory", "v252", "v253", "v254", "v255");
+#undef F_SH
+#undef F_AQ
+    return redo ? 1u : 0u;
+}
 // bits [klo, khi) of a 16-bit mask, klo / khi clamped to 0..16
 __device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
     klo = klo < 0 ? 0 : (klo > 16 ? 16 : klo); khi = khi > 16 ? 16 : (khi < 0 ? 0 : khi);
@@ -362,6 +397,11 @@ __device__ __forceinline__ uint32_t range_bits16(int32_t klo, int32_t khi) {
     (out).new_cig, 0, (out).ref_len, 0, (out).trim_flags, 0, (out).status, 0, counts, 0, (eb).ev, 0, (eb).ctr, 0, (eb).ins_at, 0, glist, 0, gcnt, 0, \
     (rd).n_reads, 0, read_base, 0, (eb).cap
 
+#if AMP_F_ADD64
+#define F_COUNT5(sq, m, d0, lim, wr) count_piece5q(sq, m, d0, lim, wr, (uint32_t)(F_REPW * 4))
+#else
+#define F_COUNT5(sq, m, d0, lim, wr) count_piece5(sq, m, d0, lim, wr)
+#endif
 template <int W>
 __global__ void __launch_bounds__(F_WAVES * 64, 2)
 k_fast(F_ARGS F_DBG_PARAM) {
@@ -373,7 +413,7 @@ k_fast(F_ARGS F_DBG_PARAM) {
     // (s_waitcnt vmcnt) unless alias scopes tell it that the access cannot touch the DMA's destination, and it only
     // builds those scopes per LDS variable.  With one struct every counter add waited for the next tile's bytes.
     __shared__ uint4 s_stage[F_WAVES][(F_PAD + F_STAGE + 16) / 16];   // per wave: the tile's quality bytes, then its packed bases
-    __shared__ uint32_t s_pwin[F_WAVES][F_REP * F_REPW];              // per wave: packed counters, byte c of a word = base c (A C G T)
+    __shared__ __attribute__((aligned(8))) uint32_t s_pwin[F_WAVES][F_REP * F_REPW];      // per wave: packed counters, byte c of a word = base c (A C G T)
     __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
     __shared__ uint32_t s_ticket, s_gcur;                             // next tile of the block to hand out; entries of its general list
 #if AMP_F_LDSPAD > 0
@@ -419,7 +459,14 @@ k_fast(F_ARGS F_DBG_PARAM) {
     // lane constants of the bank plan (see the head of this file)
     const uint32_t rep = (F_REP & (F_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F_REP : ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
+#if AMP_F_ADD64
+    // (replica r = arrays 2r -- pieces that start on an even window offset -- and 2r + 1 -- odd ones; F_REPW is odd, so the second array
+    //  starts 4 bytes off an 8-byte boundary and word p of it is 8-byte aligned for odd p)
+    lds_u8 *const wrep = (lds_u8 *)pwin + (rep & (uint32_t)(F_REP / 2 - 1)) * (uint32_t)(2 * F_REPW * 4);
+    static_assert((F_REP & 1) == 0 && (F_REPW & 1) == 1, "two arrays per replica, the second one an odd number of words behind the first");
+#else
     lds_u8 *const wrep = (lds_u8 *)pwin + rep * (uint32_t)(F_REPW * 4);
+#endif
     lds_u8 *const stage = (lds_u8 *)s_stage[wave] + F_PAD;          // the run starts here
     int32_t pw_base = 0;                                            // anchor of the wave's packed window
     int pw_tiles = F_FLUSH;                                         // tiles added since the last fold (forces an anchor for the first tile)
@@ -990,7 +1037,7 @@ k_fast(F_ARGS F_DBG_PARAM) {
             const int32_t lim16 = (int32_t)pw_lim - 16;
             if (__ballot(has_b && now)) {
                 const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
-                redo |= count_piece5(bsq, mB, dbase2 + jb, lim16, (uint32_t)(uintptr_t)wrep) << F_NP;
+                redo |= F_COUNT5(bsq, mB, dbase2 + jb, lim16, (uint32_t)(uintptr_t)wrep) << F_NP;
             }
 #else
             if (__ballot(has_b && now)) {
@@ -1007,8 +1054,8 @@ k_fast(F_ARGS F_DBG_PARAM) {
                 // (the empty asm keeps the compiler from computing the pass-independent half of every piece in front of
                 // the pass loop, which costs eighty registers this kernel does not have)
 #if AMP_F4_LEAN
-                redo |= count_piece5(s8[k], okm[k] & range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0), (second ? dbase2 : dbase1) + j0, lim16,
-                                     (uint32_t)(uintptr_t)wrep) << k;
+                redo |= F_COUNT5(s8[k], okm[k] & range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0), (second ? dbase2 : dbase1) + j0, lim16,
+                                 (uint32_t)(uintptr_t)wrep) << k;
 #else
                 asm volatile("" : "+v"(q16[k].x), "+v"(q16[k].y), "+v"(q16[k].z), "+v"(q16[k].w), "+v"(s8[k].x), "+v"(s8[k].y));
                 if (count_piece(q16[k], s8[k], j0, second ? a2 : a1, second ? b2 : b1, second ? dbase2 : dbase1)) redo |= 1u << k;

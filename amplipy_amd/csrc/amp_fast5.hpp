@@ -29,6 +29,9 @@
 
 namespace amp {
 
+#ifndef AMP_F5_ADD64
+#define AMP_F5_ADD64 1      // 64-bit counter adds where a build's replica count allows them (the eight-wave build)
+#endif
 #ifndef AMP_F5_ABL
 #define AMP_F5_ABL 0      // development builds: parts of the kernel switched off to count the rest's instructions (results are wrong on purpose)
 #endif
@@ -74,11 +77,15 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     const DevOut out{a_new_pos, a_new_ncig, a_new_cig, a_o_ref_len, a_trim_flags, a_status};
     const EventBuf eb{a_ev, a_ctr, a_ins_at, a_ev_cap};
     constexpr int F5_REPW = F5_PW + 1;        // words of a replica of the wave's packed window (replica r is skewed by r banks)
-    constexpr int F5_FLUSH = 255 / (((16 + F5_REP - 1) / F5_REP) * 4);      // (lanes go to replicas in groups of four: so many of them add into one replica at most)
+    // 64-bit adds (count_piece5q, amp_fast.hpp): a replica is two arrays, for pieces that start on an even / odd window offset; needs an
+    // even number of arrays and an odd number of words in each
+    constexpr bool F5_ADD64 = AMP_F5_ADD64 && F5_REP % 2 == 0 && F5_REPW % 2 == 1;
+    constexpr int F5_NREP = F5_ADD64 ? F5_REP / 2 : F5_REP;               // replicas a lane can be sent to
+    constexpr int F5_FLUSH = 255 / (((16 + F5_NREP - 1) / F5_NREP) * 4);      // (lanes go to replicas in groups of four: so many of them add into one array at most)
     constexpr int F5_QB = F5_PAD + F5_QRUN + 2 * F5_PAD, F5_SB = F5_PAD + F5_QRUN / 2 + F5_PAD;      // (a row's last piece is read with the 8 bytes behind it: up to 23 bytes past the run)
     __shared__ uint4 s_q[F5_WAVES][F5_QB / 16];                       // per wave: the tile's quality bytes
     __shared__ uint4 s_s[F5_WAVES][F5_SB / 16];                       // per wave: the tile's packed bases
-    __shared__ uint32_t s_pwin[F5_WAVES][F5_REP * F5_REPW];           // per wave: packed counters, byte c of a word = base c (A C G T)
+    __shared__ __attribute__((aligned(8))) uint32_t s_pwin[F5_WAVES][F5_REP * F5_REPW];           // per wave: packed counters, byte c of a word = base c (A C G T)
     __shared__ uint32_t s_bwin[F_BPL * F_BW];                         // the block's window, 32-bit counters
     __shared__ uint32_t s_ticket, s_gcur;
     unsigned long long *const ctr = eb.ctr;
@@ -115,7 +122,11 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
     // set and adds into replica (l >> 2) & 3 (replica r is skewed by r banks)
     const uint32_t rep = (F5_REP & (F5_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F5_REP : ((uint32_t)lane >> 2) & (uint32_t)(F5_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
-    const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + rep * (uint32_t)(F5_REPW * 4));
+    const uint32_t wrep = (uint32_t)(uintptr_t)((lds_u8 *)pwin + (F5_ADD64 ? (rep % (uint32_t)F5_NREP) * (uint32_t)(2 * F5_REPW * 4) : rep * (uint32_t)(F5_REPW * 4)));
+    auto count5 = [&](const uint2 &sq_, uint32_t m_, int32_t d0_, int32_t lim_) -> uint32_t {
+        if constexpr (F5_ADD64) return count_piece5q(sq_, m_, d0_, lim_, wrep, (uint32_t)(F5_REPW * 4));
+        else return count_piece5(sq_, m_, d0_, lim_, wrep);
+    };
     lds_u8 *const qst = (lds_u8 *)s_q[wave] + F5_PAD;
     lds_u8 *const sst = (lds_u8 *)s_s[wave] + F5_PAD;
     int32_t pw_base = 0;
@@ -548,7 +559,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                 const lds_u8 *sp = sst + (g.row >> 1) + (uint32_t)(g_b >> 1);
                 const uint2 sq = make_uint2(*(const lds_u32 *)sp, *(const lds_u32 *)(sp + 4));
                 const uint32_t mB = (has_b & now) ? okB & range_bits16(qa2 - jb, xbe - jb) : 0u;
-                redo |= count_piece5(sq, mB, dbase2 + jb, lim16, wrep) << F5_NP;
+                redo |= count5(sq, mB, dbase2 + jb, lim16) << F5_NP;
             }
             // The packed bases of FIVE pieces are read before their adds: LDS operations of a wave complete in order, so a read behind
             // the sixteen adds of a piece waits for every one of them (the compiler cannot see the adds and waits with lgkmcnt(0)); read
@@ -574,7 +585,7 @@ k_fast5(F_ARGS) {      // (individual arguments, like k_fast: see the note at F_
                     const int32_t j0 = (int32_t)(p * 16u);
                     const bool second = j0 >= qb1;                              // a piece behind the first segment belongs to the second
                     const uint32_t rng = range_bits16((second ? a2 : a1) - j0, (second ? b2 : b1) - j0);
-                    redo |= count_piece5(sqv[j], fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16, wrep) << k;
+                    redo |= count5(sqv[j], fo[k] & rng, (second ? dbase2 : dbase1) + j0, lim16) << k;
                 }
             }
             todo = todo & !now;
