@@ -1097,12 +1097,13 @@ static int launch_reads(amp_ctx *c, const amp_dev_reads *rd, uint64_t read_base,
     // 250 bp runs: 1.5 x and 1.3 x the first generation, which hands such reads to the general pass)
     const Fast5Cfg f5 = fast5_cfg(n, rd->n_bases_padded, c->window);
     // (a window of 8 makes the first-generation kernel spill 39 registers: 0.354 ms on the bench batch against 0.296 for the second;
-    //  windows 5 and 6 are its own, 0.274 against 0.30; with the four fixed registers of the 64-bit adds a window of 7 spills too)
+    //  windows 5-7 are its own: 0.253 / 0.269 ms at windows of 6 / 7 against 0.277 / 0.280 -- a window of 7 spills 15 registers since the
+    //  64-bit adds took four fixed ones, and is still the quicker of the two)
     // (batches of long reads with many CIGAR ops -- three a read and more: soft clips and indels everywhere, BASELINE config 5 --
     //  take the list-driven build of the second generation, amp_fast7.hpp: its tiles hold reads of one length class and none of
     //  the reads that go to the general pass; on batches of uniform long reads it is the slower one, 0.49 against 0.37 ms at 250 bp)
     const bool mixed = f5.waves != 8 && rd->n_cig >= 3 * n;
-    const int kv0 = c->kernel_variant == 0 ? (mixed ? 7 : (f5.waves == 8 && c->window < 7) ? 4 : 5) : c->kernel_variant;
+    const int kv0 = c->kernel_variant == 0 ? (mixed ? 7 : (f5.waves == 8 && c->window != 8) ? 4 : 5) : c->kernel_variant;
     const int kv1 = (kv0 >= 4 && (c->window > 8 || c->min_quality > 128)) ? 2 : kv0;
     const int kv = (kv1 == 6 && c->min_quality < 1) ? 4 : kv1;      // (the third generation tells a masked base by its zeroed code: with min_quality 0 the pad bases of a row would count as kept)
     const int variant = kv >= 5 ? 4 : kv;          // (5 and 6 differ from 4 in the fast kernel only)

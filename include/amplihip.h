@@ -249,7 +249,7 @@ int amp_debug_blocks(amp_ctx *ctx, uint32_t *out, int cap_blocks, int *n_blocks)
  * events of a batch plus 64 slots per wave of the fast kernel (8 per CU) and of the many-op kernel (24 per CU): waves
  * reserve list slots 64 at a time and leave some unused (read-out drops them). */
 int amp_reserve_events(amp_ctx *ctx, int64_t cap);
-/* 0 (default) = chosen per batch between 4, 5 and 7 by its mean padded read length (up to 152: 4), the window (7 and 8: 5) and its mean number
+/* 0 (default) = chosen per batch between 4, 5 and 7 by its mean padded read length (up to 152: 4), the window (8: 5) and its mean number
  * of CIGAR ops (long reads with three ops a read and more: 7).  4 = the fast kernel (closed-form trim +
  * pileup of reads with one match op or one insertion / deletion of up to 152 bases, every byte loaded once) followed by the
  * general pass over the reads it hands over; 5 = its second generation (reads consumed from LDS staging buffers,
