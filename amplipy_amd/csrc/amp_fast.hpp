@@ -457,7 +457,10 @@ k_fast(F_ARGS F_DBG_PARAM) {
     const int64_t wend = re;                                        // (a tile's lanes past the block's reads are idle)
     unsigned long long n_err = 0;
     // lane constants of the bank plan (see the head of this file)
-    const uint32_t rep = (F_REP & (F_REP - 1)) ? ((uint32_t)lane >> 2) % (uint32_t)F_REP : ((uint32_t)lane >> 2) & (uint32_t)(F_REP - 1);
+#ifndef AMP_F_REPSHIFT
+#define AMP_F_REPSHIFT 2
+#endif
+    const uint32_t rep = (F_REP & (F_REP - 1)) ? ((uint32_t)lane >> AMP_F_REPSHIFT) % (uint32_t)F_REP : ((uint32_t)lane >> AMP_F_REPSHIFT) & (uint32_t)(F_REP - 1);
     const uint32_t phi_lane = ((uint32_t)lane >> 1) & 1u ? 8u : 0u;
 #if AMP_F_ADD64
     // (replica r = arrays 2r -- pieces that start on an even window offset -- and 2r + 1 -- odd ones; F_REPW is odd, so the second array
